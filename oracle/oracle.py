@@ -1,0 +1,218 @@
+"""ctypes loader for the CPU oracle (oracle/cg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under iterative_solvers_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libcg_oracle.so")
+
+STOP_ITERATIONS, STOP_PRECISION, STOP_RESIDUAL, STOP_EXACT_ERROR, STOP_INTERRUPTED = range(5)
+
+
+class _Grid(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int),
+                ("a", C.c_double), ("b", C.c_double), ("c", C.c_double), ("d", C.c_double),
+                ("x_step", C.c_double), ("y_step", C.c_double),
+                ("A", C.c_double), ("x_k", C.c_double), ("y_k", C.c_double),
+                ("size", C.c_int)]
+
+
+class _MsgResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("stop_reason", C.c_int),
+                ("final_residual_norm", C.c_double), ("final_precision", C.c_double),
+                ("final_error_norm", C.c_double), ("r_norm2", C.c_double),
+                ("initial_r_norm2", C.c_double)]
+
+
+class _MfResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int),
+                ("r_norm", C.c_double), ("initial_r_norm", C.c_double)]
+
+
+_ITER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double)
+_DP = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_IP = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (make -C oracle).  Building the checker is not using it."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "cg_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        GP = C.POINTER(_Grid)
+        L.og_grid_init.argtypes = [GP, C.c_int, C.c_int] + [C.c_double] * 4
+        L.og_grid_init.restype = None
+        L.og_is_boundary.argtypes = [GP, C.c_int, C.c_int]
+        L.og_position.argtypes = [GP, C.c_int, C.c_int]
+        for name in ("og_rhs", "og_true_solution"):
+            getattr(L, name).argtypes = [GP, _DP]
+            getattr(L, name).restype = None
+        L.og_node_coords.argtypes = [GP, _DP, _DP]
+        L.og_node_coords.restype = None
+        L.og_apply.argtypes = [GP, _DP, _DP]
+        L.og_apply.restype = None
+        L.og_assemble_csr.argtypes = [GP, _IP, _IP, _DP]
+        L.og_assemble_csr.restype = C.c_long
+        L.og_mf_solve.argtypes = [GP, _DP, C.c_void_p, C.c_double, C.c_int, C.c_int,
+                                  _ITER_CB, C.c_void_p, _DP, C.POINTER(_MfResult)]
+        L.og_mf_solve.restype = None
+        L.og_msg_solve.argtypes = [GP, _DP, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                   C.c_int, _ITER_CB, C.c_void_p, C.c_void_p, _DP, C.c_void_p,
+                                   C.POINTER(_MsgResult)]
+        L.og_msg_solve.restype = None
+        L.og_dot.argtypes = [_DP, _DP, C.c_long]
+        L.og_dot.restype = C.c_double
+        L.og_max_norm.argtypes = [_DP, C.c_long]
+        L.og_max_norm.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+@dataclass
+class MsgResult:
+    x: np.ndarray
+    r: np.ndarray
+    iterations: int
+    converged: bool
+    stop_reason: int
+    final_residual_norm: float
+    final_precision: float
+    final_error_norm: float
+    r_norm2: float
+    initial_r_norm2: float
+    callbacks: list
+
+
+@dataclass
+class MfResult:
+    x: np.ndarray
+    iterations: int
+    converged: bool
+    r_norm: float
+    initial_r_norm: float
+    callbacks: list
+
+
+class OracleGrid:
+    """MatrixFreeSystem / GridSystem restated (ctor argument order is (m, n, a, b, c, d))."""
+
+    def __init__(self, m: int, n: int, a: float = 1.0, b: float = 2.0, c: float = 1.0, d: float = 2.0):
+        self._g = _Grid()
+        lib().og_grid_init(C.byref(self._g), m, n, a, b, c, d)
+
+    @property
+    def size(self) -> int:
+        return self._g.size
+
+    @property
+    def coeffs(self):
+        return self._g.A, self._g.x_k, self._g.y_k
+
+    def position(self, x: int, y: int) -> int:
+        return lib().og_position(C.byref(self._g), x, y)
+
+    def is_boundary(self, x: int, y: int) -> bool:
+        return bool(lib().og_is_boundary(C.byref(self._g), x, y))
+
+    def rhs(self) -> np.ndarray:
+        out = np.empty(self.size)
+        lib().og_rhs(C.byref(self._g), out)
+        return out
+
+    def true_solution(self) -> np.ndarray:
+        out = np.empty(self.size)
+        lib().og_true_solution(C.byref(self._g), out)
+        return out
+
+    def node_coords(self):
+        xs, ys = np.empty(self.size), np.empty(self.size)
+        lib().og_node_coords(C.byref(self._g), xs, ys)
+        return xs, ys
+
+    def apply(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.size,)
+        y = np.empty(self.size)
+        lib().og_apply(C.byref(self._g), x, y)
+        return y
+
+    def dense(self) -> np.ndarray:
+        """Operator as a dense matrix by unit-vector probing (small grids only)."""
+        n = self.size
+        A = np.empty((n, n))
+        for j in range(n):
+            e = np.zeros(n)
+            e[j] = 1.0
+            A[:, j] = self.apply(e)
+        return A
+
+    def csr(self):
+        row_map = np.zeros(self.size + 1, dtype=np.int32)
+        entries = np.zeros(5 * self.size, dtype=np.int32)
+        values = np.zeros(5 * self.size)
+        nnz = lib().og_assemble_csr(C.byref(self._g), row_map, entries, values)
+        return row_map, entries[:nnz].copy(), values[:nnz].copy()
+
+    def mf_solve(self, b=None, true_solution=None, eps=1e-6, max_iterations=10000,
+                 diagnostics=False) -> MfResult:
+        """MatrixFreeSolver::solve (relative 2-norm stop rule)."""
+        b = self.rhs() if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        u = self.true_solution() if true_solution is None else np.ascontiguousarray(true_solution)
+        x = np.empty(self.size)
+        res = _MfResult()
+        cbs = []
+        cb = _ITER_CB(lambda user, it, p, r, e: cbs.append((it, p, r, e)))
+        lib().og_mf_solve(C.byref(self._g), b, u.ctypes.data, eps, max_iterations,
+                          1 if diagnostics else 0, cb, None, x, C.byref(res))
+        return MfResult(x, res.iterations, bool(res.converged), res.r_norm, res.initial_r_norm, cbs)
+
+    def msg_solve(self, b=None, true_solution="default", eps_precision=1e-6, eps_residual=1e-6,
+                  eps_exact_error=-1.0, max_iterations=10000) -> MsgResult:
+        """MSGSolver::solve (absolute max-norm stop rules)."""
+        b = self.rhs() if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        if isinstance(true_solution, str):
+            true_solution = self.true_solution()
+        uptr = None
+        if true_solution is not None:
+            true_solution = np.ascontiguousarray(true_solution, dtype=np.float64)
+            uptr = true_solution.ctypes.data
+        x = np.empty(self.size)
+        r = np.empty(self.size)
+        res = _MsgResult()
+        cbs = []
+        cb = _ITER_CB(lambda user, it, p, rr, e: cbs.append((it, p, rr, e)))
+        lib().og_msg_solve(C.byref(self._g), b, uptr, eps_precision, eps_residual, eps_exact_error,
+                           max_iterations, cb, None, None, x, r.ctypes.data, C.byref(res))
+        return MsgResult(x, r, res.iterations, bool(res.converged), res.stop_reason,
+                         res.final_residual_norm, res.final_precision, res.final_error_norm,
+                         res.r_norm2, res.initial_r_norm2, cbs)
+
+
+def dot(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return lib().og_dot(a, b, a.size)
+
+
+def max_norm(a: np.ndarray) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return lib().og_max_norm(a, a.size)
