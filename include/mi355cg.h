@@ -1,0 +1,135 @@
+/*
+ * mi355cg.h -- C ABI of libmi355cg.so: the MI355X (gfx950) matrix-free conjugate-gradient
+ * path for the 2-D Dirichlet Poisson problem on the reference's L-shaped grid.
+ *
+ * This is the drop-in boundary underneath the reference's C++ plug-in interfaces.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   mi355cg_create / _destroy      GridSystem::GridSystem(m,n,a,b,c,d)      solver/grid_system.cpp:301-322
+ *                                  MatrixFreeSystem::MatrixFreeSystem       solver/matrix_free_system.cpp:144-159
+ *   mi355cg_size                   MatrixFreeSystem::size / matrix.numRows  solver/matrix_free_system.hpp:66
+ *   mi355cg_get_rhs                GridSystem::get_rhs / MatrixFreeSystem::get_rhs   grid_system.h:73, matrix_free_system.hpp:49
+ *   mi355cg_get_true_solution      get_true_solution_vector                 grid_system.cpp:276-299, matrix_free_system.cpp:162-199
+ *   mi355cg_get_node_coords        GridSystem::get_x_coords/get_y_coords    grid_system.cpp:189-190,235-236
+ *   mi355cg_set_rhs                Solver(a, b, ...) caller-supplied b      solver/solver.hpp:33-39
+ *   mi355cg_apply                  MatrixFreeSystem::apply(x, y)            solver/matrix_free_system.cpp:203-340
+ *                                  KokkosSparse::spmv("N",1,A,z,0,A_z)      solver/msg_solver.cpp:93
+ *   mi355cg_solve                  MSGSolver::solve(true_solution)          solver/msg_solver.cpp:10-212   (rule MSG_MAXNORM)
+ *                                  MatrixFreeSolver::solve(true_solution)   solver/matrix_free_system.cpp:383-482 (rule REL_2NORM)
+ *   mi355cg_get_solution/_residual DirichletSolver::getSolution, computeResidual (A x - b)   solver/dirichlet_solver.cpp:147-161,183-191
+ *   mi355cg_iter_cb                Solver::setIterationCallback             solver/solver.hpp:46-50
+ *   stop_flag                      MSGSolver::requestStop (atomic flag)     solver/msg_solver.hpp:35,76; msg_solver.cpp:82-87
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All host vectors are in the reference's
+ * PACKED unknown order (bottom-right block row-major, then the upper block row-major;
+ * grid_system.cpp:84-111) and are caller-owned.  Every function returns MI355CG_OK (0) or an
+ * error code; mi355cg_last_error() gives the text (thread-local).  There is no CPU fallback:
+ * without a usable HIP device every compute entry point fails with MI355CG_ERR_HIP.
+ */
+#ifndef MI355CG_H
+#define MI355CG_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355CG_OK            0
+#define MI355CG_ERR_INVALID   1   /* bad argument (std::invalid_argument in the C++ wrapper)    */
+#define MI355CG_ERR_HIP       2   /* HIP runtime failure / no device (std::runtime_error)       */
+#define MI355CG_ERR_STATE     3   /* call order (e.g. get_solution before solve)                */
+
+/* storage / arithmetic type of the CG vectors */
+#define MI355CG_F64           0   /* fp64 storage and arithmetic: the parity path               */
+#define MI355CG_F32_MIXED     1   /* fp32 inner CG, fp64 residual refinement (no reference twin) */
+
+/* stop rule */
+#define MI355CG_RULE_MSG_MAXNORM  0   /* MSGSolver: absolute max-norm criteria, strict <        */
+#define MI355CG_RULE_REL_2NORM    1   /* MatrixFreeSolver: ||r||_2 > eps * ||r0||_2             */
+
+/* StopCriterion, solver/msg_solver.hpp:9-15 (same order) */
+#define MI355CG_STOP_ITERATIONS   0
+#define MI355CG_STOP_PRECISION    1
+#define MI355CG_STOP_RESIDUAL     2
+#define MI355CG_STOP_EXACT_ERROR  3
+#define MI355CG_STOP_INTERRUPTED  4
+
+typedef struct mi355cg_ctx *mi355cg_handle;
+
+/* (iteration, ||x_n - x_{n-1}||, ||residual||, ||x - u||), invoked on the thread that called
+ * mi355cg_solve.  MSG rule: max-norms, at it = 0, 1, every callback_every-th and the final one
+ * (msg_solver.cpp:75-77,172-183,193-195).  REL_2NORM rule with diagnostics: 2-norms, the TRUE
+ * residual b - A x, every iteration, 0-based index (matrix_free_system.cpp:466-468). */
+typedef void (*mi355cg_iter_cb)(void *user, int iteration, double precision, double residual, double error);
+
+typedef struct mi355cg_params {
+    int    rule;               /* MI355CG_RULE_*                                                 */
+    int    max_iterations;     /* Solver::maxIterations                                          */
+    double eps_precision;      /* MSG: <= 0 disables (msg_solver.cpp:144)                        */
+    double eps_residual;       /* MSG: <= 0 disables (:151)                                      */
+    double eps_exact_error;    /* MSG: <= 0 disables (:158)                                      */
+    double eps_rel;            /* REL_2NORM: eps of matrix_free_system.cpp:409                   */
+    int    use_true_solution;  /* MSG: true_solution.extent(0) > 0 (:64,132,158)                 */
+    int    callback_every;     /* MSG cadence (reference: 100); 0 = only it 0/1/final            */
+    int    diagnostics;        /* REL_2NORM: reproduce the per-iteration diagnostics + callback  */
+    int    sync_every;         /* iterations enqueued between host polls; 0 = automatic          */
+    int    fixed_iterations;   /* bench mode: ignore every convergence test, run max_iterations  */
+} mi355cg_params;
+
+typedef struct mi355cg_results {
+    int    iterations;
+    int    converged;
+    int    stop_reason;           /* MI355CG_STOP_*                                              */
+    double final_residual_norm;   /* MSG: max-norm of the recursive residual (msg_solver.cpp:188) */
+    double final_precision;       /* MSG: max-norm of x_n - x_{n-1} (:189); DBL_MAX if none      */
+    double final_error_norm;      /* MSG: max-norm of x - u (:190); DBL_MAX without u            */
+    double r_norm2;               /* Euclidean norm of the recursive residual                    */
+    double initial_r_norm2;       /* ||r0||_2                                                    */
+    double solve_seconds;         /* wall time of the device loop (init .. last poll)            */
+    double refine_true_rel;       /* F32_MIXED: final fp64 ||b-Ax||_2/||b||_2, else 0            */
+    int    refine_outer;          /* F32_MIXED: outer refinement steps, else 0                   */
+} mi355cg_results;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* Argument order follows DirichletSolver(n, m, a, b, c, d) (dirichlet_solver.cpp:11); only
+ * n == m, even, >= 6 is accepted (the reference's index map is only consistent there).         */
+int  mi355cg_create(int n, int m, double a, double b, double c, double d,
+                    int dtype, int device, mi355cg_handle *out);
+void mi355cg_destroy(mi355cg_handle h);
+const char *mi355cg_last_error(void);
+const char *mi355cg_version(void);
+
+/* ---- setup data (host, packed order, length mi355cg_size) ------------------------------------ */
+long long mi355cg_size(mi355cg_handle h);
+int  mi355cg_get_rhs(mi355cg_handle h, double *out);
+int  mi355cg_get_true_solution(mi355cg_handle h, double *out);
+int  mi355cg_get_node_coords(mi355cg_handle h, double *xs, double *ys);
+int  mi355cg_set_rhs(mi355cg_handle h, const double *b);
+
+/* ---- operator -------------------------------------------------------------------------------- */
+int  mi355cg_apply(mi355cg_handle h, const double *x, double *y);            /* host buffers   */
+int  mi355cg_apply_device(mi355cg_handle h, const double *x_dev, double *y_dev); /* packed, device */
+
+/* ---- solver ---------------------------------------------------------------------------------- */
+void mi355cg_default_params(mi355cg_params *p, int rule);
+int  mi355cg_solve(mi355cg_handle h, const mi355cg_params *params,
+                   mi355cg_iter_cb cb, void *user, const volatile int *stop_flag,
+                   mi355cg_results *out);
+int  mi355cg_get_solution(mi355cg_handle h, double *x);         /* packed x of the last solve   */
+int  mi355cg_get_recursive_residual(mi355cg_handle h, double *r);
+int  mi355cg_get_true_residual(mi355cg_handle h, double *ax_minus_b); /* A x - b, one more apply */
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
+/* Per-kernel device time of the last mi355cg_solve, measured with HIP events on the solve
+ * stream when profiling was enabled.  kernel: 0 = fused stencil (A'), 1 = fused update (B).   */
+int  mi355cg_set_profiling(mi355cg_handle h, int enable);
+int  mi355cg_get_kernel_time(mi355cg_handle h, int kernel, double *avg_ms, long long *launches);
+/* launch geometry: bytes of storage per vector, padded length, grid sizes (for DESIGN/bench)   */
+int  mi355cg_get_layout(mi355cg_handle h, long long *padded_len, int *pitch_bottom, int *pitch_upper,
+                        int *grid_stencil, int *grid_update, int *rows_per_item);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355CG_H */

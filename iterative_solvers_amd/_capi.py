@@ -1,0 +1,97 @@
+"""ctypes binding of include/mi355cg.h (libmi355cg.so).  Fails loudly when the HIP library is
+missing or unusable: there is no CPU path in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+OK, ERR_INVALID, ERR_HIP, ERR_STATE = 0, 1, 2, 3
+F64, F32_MIXED = 0, 1
+RULE_MSG_MAXNORM, RULE_REL_2NORM = 0, 1
+STOP_ITERATIONS, STOP_PRECISION, STOP_RESIDUAL, STOP_EXACT_ERROR, STOP_INTERRUPTED = range(5)
+
+EXPORTS = [
+    "mi355cg_create", "mi355cg_destroy", "mi355cg_last_error", "mi355cg_version", "mi355cg_size",
+    "mi355cg_get_rhs", "mi355cg_get_true_solution", "mi355cg_get_node_coords", "mi355cg_set_rhs",
+    "mi355cg_apply", "mi355cg_apply_device", "mi355cg_default_params", "mi355cg_solve",
+    "mi355cg_get_solution", "mi355cg_get_recursive_residual", "mi355cg_get_true_residual",
+    "mi355cg_set_profiling", "mi355cg_get_kernel_time", "mi355cg_get_layout",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("rule", C.c_int), ("max_iterations", C.c_int),
+                ("eps_precision", C.c_double), ("eps_residual", C.c_double),
+                ("eps_exact_error", C.c_double), ("eps_rel", C.c_double),
+                ("use_true_solution", C.c_int), ("callback_every", C.c_int),
+                ("diagnostics", C.c_int), ("sync_every", C.c_int), ("fixed_iterations", C.c_int)]
+
+
+class Results(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("stop_reason", C.c_int),
+                ("final_residual_norm", C.c_double), ("final_precision", C.c_double),
+                ("final_error_norm", C.c_double), ("r_norm2", C.c_double),
+                ("initial_r_norm2", C.c_double), ("solve_seconds", C.c_double),
+                ("refine_true_rel", C.c_double), ("refine_outer", C.c_int)]
+
+
+ITER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double)
+_DP = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+_lib = None
+
+
+class Mi355cgError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        super().__init__(f"mi355cg error {code}: {text}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libmi355cg.so (building it with hipcc first when the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if _build.needs_build():
+        try:
+            _build.build()
+        except Exception as e:  # pre-built .so shipped to a box without hipcc is fine
+            if not os.path.exists(path):
+                raise RuntimeError(f"libmi355cg.so is missing and could not be built: {e}") from e
+    L = C.CDLL(path)
+    H = C.c_void_p
+    L.mi355cg_create.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.POINTER(H)]
+    L.mi355cg_destroy.argtypes = [H]
+    L.mi355cg_destroy.restype = None
+    L.mi355cg_last_error.restype = C.c_char_p
+    L.mi355cg_version.restype = C.c_char_p
+    L.mi355cg_size.argtypes = [H]
+    L.mi355cg_size.restype = C.c_longlong
+    for name in ("mi355cg_get_rhs", "mi355cg_get_true_solution", "mi355cg_set_rhs",
+                 "mi355cg_get_solution", "mi355cg_get_recursive_residual", "mi355cg_get_true_residual"):
+        getattr(L, name).argtypes = [H, _DP]
+    L.mi355cg_get_node_coords.argtypes = [H, _DP, _DP]
+    L.mi355cg_apply.argtypes = [H, _DP, _DP]
+    L.mi355cg_apply_device.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.mi355cg_default_params.argtypes = [C.POINTER(Params), C.c_int]
+    L.mi355cg_default_params.restype = None
+    L.mi355cg_solve.argtypes = [H, C.POINTER(Params), ITER_CB, C.c_void_p, C.c_void_p, C.POINTER(Results)]
+    L.mi355cg_set_profiling.argtypes = [H, C.c_int]
+    L.mi355cg_get_kernel_time.argtypes = [H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.mi355cg_get_layout.argtypes = [H, C.POINTER(C.c_longlong)] + [C.POINTER(C.c_int)] * 5
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != OK:
+        raise Mi355cgError(rc, load().mi355cg_last_error().decode("utf-8", "replace"))

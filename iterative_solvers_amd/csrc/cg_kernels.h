@@ -1,0 +1,480 @@
+// cg_kernels.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the matrix-free CG path.
+//
+//   k_stencil  (phase A')  p_new = r + beta*p_old (fused, halo recomputed), Ap = A_h p_new,
+//                          partial sums of (Ap,p) and (r,p).  Replaces MatrixFreeSystem::apply
+//                          (matrix_free_system.cpp:203-340) / KokkosSparse::spmv (msg_solver.cpp:93),
+//                          the direction update (matrix_free_system.cpp:436-438, msg_solver.cpp:167-169)
+//                          and the two dots (matrix_free_system.cpp:417, msg_solver.cpp:96,99).
+//   k_update   (phase B)   x += alpha p, r -= alpha Ap, partial sums/maxes of r.r, |r|, |dx|, |x-u|.
+//                          Replaces matrix_free_system.cpp:422-455 / msg_solver.cpp:105-139.
+//   k_check, k_reduce_parts, k_pack/k_unpack, k_sub, k_resid2: small helpers.
+//
+// Bandwidth-bound stencil: no MFMA.  All arithmetic that the reference does element-wise is
+// done in the reference's operation order without FMA contraction (-ffp-contract=off), so
+// vectors are bit-identical to the CPU oracle for equal scalars; only the inner products use a
+// different (fixed, deterministic) summation tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cmath>
+
+namespace mi355cg {
+
+constexpr int kBlock = 256;           // threads per workgroup = 4 wave64
+constexpr int kWave = 64;
+constexpr int kWaves = kBlock / kWave;
+constexpr int kHist = 512;            // per-iteration norm history ring (>= sync_every)
+constexpr int kMaxPanels = 6;
+
+// ---- storage layout -------------------------------------------------------------------------------
+// Node (x, y) of the (N+1)x(N+1) bounding grid lives at  row_off(y) + x - base0.  Rows y <= N/2
+// (bottom-right block + its boundary row 0) only store columns [cb, cb+Pb), cb = N/2 rounded down
+// to 32; rows above store columns [0, Pu).  Pb, Pu, cb are multiples of 32 elements so every row
+// starts 256-B aligned.  Boundary nodes and pads hold 0 and stay 0; Dirichlet data is in the RHS.
+struct Geom {
+    int N, half, cb, xlim;            // xlim: columns [0, xlim) are touched by the stencil strips
+    int Pb, Pu;                       // row pitches (elements) of bottom / upper rows
+    int y_lo, y_hi;                   // owned rows (inclusive); rows y_lo-1 and y_hi+1 are ghosts
+    long long base0;                  // physical offset of the first stored element (row y_lo-1)
+    long long own_begin, own_len;     // flat [begin, begin+len) of the owned rows, local offsets
+    double A, xk, yk;                 // stencil coefficients (grid_system.cpp:316-318)
+};
+
+__host__ __device__ inline long long row_off(const Geom& g, int y) {
+    return y <= g.half ? (long long)y * g.Pb - g.cb
+                       : (long long)(g.half + 1) * g.Pb + (long long)(y - g.half - 1) * g.Pu;
+}
+__host__ __device__ inline bool node_interior(const Geom& g, int x, int y) {
+    return y >= 1 && y <= g.N - 1 && x <= g.N - 1 && x >= (y <= g.half ? g.half + 1 : 1);
+}
+
+// A panel is a rectangle of owned rows x column strips, cut into row chunks; one (chunk, strip)
+// pair is one work item = one wave marching down `ty` rows of a 64*VEC-column strip.
+struct Panel { int y0, y1, s0, ns, ty, nchunks, item0; };
+struct WorkList { Panel p[kMaxPanels]; int np; int nitems; };
+
+// ---- CG state carried on the device ----------------------------------------------------------------
+struct CgState {
+    double alpha, beta;
+    double rr;          // (r, r) of the current residual
+    double rz;          // MSG: (r, z) of the current iteration (denominator of the next beta)
+    double r0norm;      // ||r0||_2
+    double rnorm2;      // ||r||_2
+    double rmax, dmax, emax, d2, e2;
+    int it, done, reason, converged, first, pad_;
+};
+struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2; };
+
+struct RuleParams {
+    int rule;                 // MI355CG_RULE_*
+    int max_iterations;
+    double eps_precision, eps_residual, eps_exact_error, eps_rel;
+    int use_u;
+    int fixed_iterations;
+};
+
+// partial-sum fields, field-major: part[field * stride + block]
+enum { FA_PAP = 0, FA_RZ = 1, FA_COUNT = 2 };
+enum { FB_RR = 0, FB_RMAX = 1, FB_DMAX = 2, FB_EMAX = 3, FB_D2 = 4, FB_E2 = 5, FB_COUNT = 6 };
+
+// ---- block-level deterministic reductions ----------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+    return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, kWave));
+    return v;
+}
+// All threads get the block total.  Fixed tree: lane tree inside a wave, then waves 0..3 in order.
+template <bool IS_MAX>
+__device__ inline double block_reduce(double v, double* lds /* >= kWaves doubles */) {
+    v = IS_MAX ? wave_max(v) : wave_sum(v);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    __syncthreads();                       // protect lds from the previous use
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double t = lds[0];
+#pragma unroll
+    for (int k = 1; k < kWaves; ++k) t = IS_MAX ? fmax(t, lds[k]) : t + lds[k];
+    return t;
+}
+// Reduce `n` partials of one field (thread t takes t, t+256, ... in ascending order).
+template <bool IS_MAX>
+__device__ inline double reduce_parts(const double* __restrict__ part, int n, double* lds) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += kBlock) v = IS_MAX ? fmax(v, part[i]) : v + part[i];
+    return block_reduce<IS_MAX>(v, lds);
+}
+
+// ---- the decision taken after every update: convergence tests, beta ------------------------------
+// Mirrors msg_solver.cpp:144-165 / matrix_free_system.cpp:409,432-433,441,472.  Every block
+// evaluates it from the same reduced numbers, so all blocks agree.
+struct Decision { int done, reason, converged; double beta, rr, rnorm2, r0norm, rmax, dmax, emax, d2, e2; };
+
+__device__ inline Decision decide_after_update(const CgState& s, const RuleParams& rp, double rr, double rmax,
+                                               double dmax, double emax, double d2, double e2) {
+    Decision d;
+    d.rr = rr; d.rnorm2 = sqrt(rr); d.rmax = rmax; d.dmax = dmax; d.emax = emax; d.d2 = d2; d.e2 = e2;
+    d.r0norm = s.first ? d.rnorm2 : s.r0norm;
+    d.done = 0; d.reason = 0 /*ITERATIONS*/; d.converged = 0; d.beta = 0.0;
+    if (rp.rule == 1 /*REL_2NORM*/) {
+        // for (...; iterations < maxIterations && r_norm > eps * initial_r_norm; ...)  :409
+        const bool go = s.it < rp.max_iterations && (rp.fixed_iterations || d.rnorm2 > rp.eps_rel * d.r0norm);
+        if (!go) { d.done = 1; d.converged = d.rnorm2 <= rp.eps_rel * d.r0norm; }     // :472
+        if (!s.first) d.beta = rr / s.rr;                                               // :432-433
+    } else {
+        if (s.it >= 1 && !rp.fixed_iterations) {
+            if (rp.eps_precision > 0 && dmax < rp.eps_precision) { d.done = 1; d.converged = 1; d.reason = 1; }
+            else if (rp.eps_residual > 0 && rmax < rp.eps_residual) { d.done = 1; d.converged = 1; d.reason = 2; }
+            else if (rp.eps_exact_error > 0 && rp.use_u && emax < rp.eps_exact_error) { d.done = 1; d.converged = 1; d.reason = 3; }
+        }
+        if (!d.done && !(s.it < rp.max_iterations)) d.done = 1;                         // while (it < maxIterations) :80
+        if (!s.first) d.beta = (d.rnorm2 * d.rnorm2) / s.rz;                            // :165
+    }
+    return d;
+}
+
+__device__ inline void write_state_after_decision(CgState* out, HistEntry* hist, const CgState& s, const Decision& d) {
+    CgState o = s;
+    o.rr = d.rr; o.rnorm2 = d.rnorm2; o.r0norm = d.r0norm; o.beta = d.beta;
+    o.rmax = d.rmax; o.dmax = d.dmax; o.emax = d.emax; o.d2 = d.d2; o.e2 = d.e2;
+    o.done = d.done; o.reason = d.reason; o.converged = d.converged;
+    *out = o;
+    if (hist) {
+        HistEntry h; h.dmax = d.dmax; h.rmax = d.rmax; h.emax = d.emax; h.rnorm2 = d.rnorm2; h.d2 = d.d2; h.e2 = d.e2;
+        hist[s.it % kHist] = h;
+    }
+}
+
+// Reduce the update kernel's partials (only the fields the rule needs) and decide.
+__device__ inline Decision reduce_and_decide(const CgState& s, const RuleParams& rp, const double* partB,
+                                             int nB, int strideB, int want_diag, double* lds) {
+    const double rr = reduce_parts<false>(partB + FB_RR * strideB, nB, lds);
+    double rmax = 0, dmax = 0, emax = 0, d2 = 0, e2 = 0;
+    if (rp.rule == 0 || want_diag) {
+        rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, lds);
+        dmax = reduce_parts<true>(partB + FB_DMAX * strideB, nB, lds);
+        if (rp.use_u) emax = reduce_parts<true>(partB + FB_EMAX * strideB, nB, lds);
+    }
+    if (want_diag) {
+        d2 = reduce_parts<false>(partB + FB_D2 * strideB, nB, lds);
+        if (rp.use_u) e2 = reduce_parts<false>(partB + FB_E2 * strideB, nB, lds);
+    }
+    return decide_after_update(s, rp, rr, rmax, dmax, emax, d2, e2);
+}
+
+// ---- phase A': fused direction update + 5-point stencil + dots ------------------------------------
+template <typename T>
+struct StencilArgs {
+    Geom g;
+    WorkList wl;
+    const T* r;          // FUSED: residual (with ghost rows); PLAIN: unused
+    const T* pin;        // FUSED: previous direction; PLAIN: the vector to apply the operator to
+    T* pout;             // FUSED: new direction (ping-pong partner of pin)
+    T* ap;               // A_h * (new direction | input vector)
+    const double* partB; int nB, strideB;       // update-kernel partials to reduce in the prologue
+    double* partA; int strideA;                 // this kernel's partials (field-major)
+    const CgState* s_in; CgState* s_out;        // state written by the update kernel / by this kernel
+    HistEntry* hist;
+    RuleParams rp;
+    int want_diag;
+};
+
+template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
+
+template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH>
+__global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
+    typedef typename VecOf<T, VEC>::type vec_t;
+    __shared__ double lds[kWaves];
+    const Geom& g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR item decode
+
+    T beta = (T)0;
+    if (FUSED) {
+        const CgState s = *a.s_in;
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+        const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.want_diag, lds);
+        if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, s, d);
+        if (d.done) return;
+        beta = (T)d.beta;
+    }
+
+    const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
+    double acc_pap = 0.0, acc_rz = 0.0;
+
+    struct Raw { vec_t r, p; T re, pe; };
+
+    for (int item = blockIdx.x * kWaves + wave; item < a.wl.nitems; item += gridDim.x * kWaves) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxPanels; ++k) if (k < a.wl.np && item >= a.wl.p[k].item0) pi = k;
+        const Panel P = a.wl.p[pi];
+        const int local = item - P.item0;
+        const int chunk = local / P.ns;
+        const int strip = P.s0 + (local - chunk * P.ns);
+        const int ya = P.y0 + chunk * P.ty;
+        const int yb = min(P.y1, ya + P.ty - 1);
+        const int x = strip * (kWave * VEC) + lane * VEC;
+        const bool xin = x < g.xlim;
+        const bool edge = (lane == 0) || (lane == kWave - 1);
+        const int xe = lane == 0 ? x - 1 : x + VEC;
+
+        auto fetch = [&](int y, bool with_edge) -> Raw {
+            Raw w;
+            const int cmin = y <= g.half ? g.cb : 0;
+            const long long off = row_off(g, y) - g.base0;
+            const bool v = xin && x >= cmin;
+            vec_t z; for (int j = 0; j < VEC; ++j) z[j] = (T)0;
+            w.p = v ? *reinterpret_cast<const vec_t*>(a.pin + off + x) : z;
+            if (FUSED) w.r = v ? *reinterpret_cast<const vec_t*>(a.r + off + x) : z; else w.r = z;
+            w.re = (T)0; w.pe = (T)0;
+            if (with_edge && edge && xe >= cmin && xe < g.xlim) {
+                w.pe = a.pin[off + xe];
+                if (FUSED) w.re = a.r[off + xe];
+            }
+            return w;
+        };
+        auto conv = [&](const Raw& w, vec_t& pn, T& pne) {
+            if (FUSED) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) pn[j] = w.r[j] + beta * w.p[j];
+                pne = w.re + beta * w.pe;
+            } else { pn = w.p; pne = w.pe; }
+        };
+
+        Raw q[DEPTH];
+        vec_t pn_m, pn_c, pn_p, r_c;
+        T pne_c, pne_p, dummy;
+        {
+            const Raw wm = fetch(ya - 1, false);
+            const Raw wc = fetch(ya, true);
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                if (ya + 1 + k <= yb + 1) q[k] = fetch(ya + 1 + k, true);
+                else { Raw zz; for (int j = 0; j < VEC; ++j) { zz.r[j] = (T)0; zz.p[j] = (T)0; } zz.re = zz.pe = (T)0; q[k] = zz; }
+            }
+            conv(wm, pn_m, dummy);
+            conv(wc, pn_c, pne_c);
+            r_c = wc.r;
+        }
+
+        for (int yy = ya; yy <= yb; yy += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const int y = yy + k;
+                if (y <= yb) {
+                    const Raw w = q[k];
+                    if (y + 1 + DEPTH <= yb + 1) q[k] = fetch(y + 1 + DEPTH, true);
+                    conv(w, pn_p, pne_p);
+
+                    // in-row neighbours: from the adjacent lane, wave-edge lanes use their edge load
+                    T left0 = __shfl_up(pn_c[VEC - 1], 1, kWave);
+                    T rightL = __shfl_down(pn_c[0], 1, kWave);
+                    if (lane == 0) left0 = pne_c;
+                    if (lane == kWave - 1) rightL = pne_c;
+
+                    const int cmin = y <= g.half ? g.cb : 0;
+                    const int xint0 = y <= g.half ? g.half + 1 : 1;     // first interior column of row y
+                    vec_t out;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const T c = pn_c[j];
+                        const T L = j == 0 ? left0 : pn_c[j - 1];
+                        const T R = j == VEC - 1 ? rightL : pn_c[j + 1];
+                        // y[row] += A*x[row]; += x_k*left; += x_k*right; += y_k*top; += y_k*bottom
+                        T v = cA * c;
+                        v = v + cxk * L;
+                        v = v + cxk * R;
+                        v = v + cyk * pn_p[j];
+                        v = v + cyk * pn_m[j];
+                        const int xj = x + j;
+                        out[j] = (xj >= xint0 && xj <= g.N - 1) ? v : (T)0;
+                        acc_pap += (double)c * (double)out[j];
+                        if (MSG) acc_rz += (double)r_c[j] * (double)c;
+                    }
+                    if (xin && x >= cmin) {
+                        const long long off = row_off(g, y) - g.base0 + x;
+                        *reinterpret_cast<vec_t*>(a.ap + off) = out;
+                        if (FUSED) *reinterpret_cast<vec_t*>(a.pout + off) = pn_c;
+                    }
+                    pn_m = pn_c; pn_c = pn_p; pne_c = pne_p; r_c = w.r;
+                }
+            }
+        }
+    }
+
+    const double tp = block_reduce<false>(acc_pap, lds);
+    double tz = 0.0;
+    if (MSG) tz = block_reduce<false>(acc_rz, lds);
+    if (threadIdx.x == 0 && a.partA) {
+        a.partA[FA_PAP * a.strideA + blockIdx.x] = tp;
+        a.partA[FA_RZ * a.strideA + blockIdx.x] = tz;
+    }
+}
+
+// ---- phase B: fused x / r update + norms -----------------------------------------------------------
+template <typename T>
+struct UpdateArgs {
+    long long begin, nvec;     // owned flat range in units of VEC elements (begin is a vec index)
+    T* x; T* r; const T* p; const T* ap; const T* u;
+    const double* partA; int nA, strideA;
+    double* partB; int strideB;
+    const CgState* s_in; CgState* s_out;
+    int rule;                  // MSG: alpha = rz / Azz ; REL2: alpha = rr / pAp
+    int init;                  // 1: alpha := 0, state initialisation (x = 0, r = b)
+};
+
+template <typename T, int VEC, bool HAS_U>
+__global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
+    typedef typename VecOf<T, VEC>::type vec_t;
+    __shared__ double lds[kWaves];
+    CgState s;
+    double alpha_d = 0.0, rz = 0.0;
+    if (a.init) {
+        s = CgState{}; s.first = 1; s.it = 0;
+    } else {
+        s = *a.s_in;
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, lds);
+        if (a.rule == 0) {
+            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, lds);
+            alpha_d = rz / pap;                       // msg_solver.cpp:102
+        } else {
+            alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
+        }
+    }
+    const T alpha = (T)alpha_d;
+
+    double s_rr = 0, s_rmax = 0, s_dmax = 0, s_emax = 0, s_d2 = 0, s_e2 = 0;
+    const long long stride = (long long)gridDim.x * kBlock;
+    vec_t* X = reinterpret_cast<vec_t*>(a.x);
+    vec_t* R = reinterpret_cast<vec_t*>(a.r);
+    const vec_t* Pp = reinterpret_cast<const vec_t*>(a.p);
+    const vec_t* Q = reinterpret_cast<const vec_t*>(a.ap);
+    const vec_t* Uu = reinterpret_cast<const vec_t*>(a.u);
+
+    auto body = [&](long long i) {
+        const vec_t x0 = X[i], pv = Pp[i], r0 = R[i], qv = Q[i];
+        vec_t uv; if (HAS_U) uv = Uu[i];
+        vec_t xn, rn;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            xn[j] = x0[j] + alpha * pv[j];            // x = x + alpha*z        msg_solver.cpp:105-107
+            rn[j] = r0[j] - alpha * qv[j];            // r = r - alpha*A_z      msg_solver.cpp:110-112
+            const double rd = (double)rn[j];
+            s_rr += rd * rd;
+            s_rmax = fmax(s_rmax, fabs(rd));
+            const double dd = (double)(xn[j] - x0[j]); // diff = x - x_prev     msg_solver.cpp:124-127
+            s_dmax = fmax(s_dmax, fabs(dd));
+            s_d2 += dd * dd;
+            if (HAS_U) {
+                const double ee = (double)(xn[j] - uv[j]);   // error = x - u   msg_solver.cpp:132-136
+                s_emax = fmax(s_emax, fabs(ee));
+                s_e2 += ee * ee;
+            }
+        }
+        X[i] = xn; R[i] = rn;
+    };
+    long long i = a.begin + (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long end = a.begin + a.nvec;
+    for (; i + stride < end; i += 2 * stride) { body(i); body(i + stride); }
+    if (i < end) body(i);
+
+    const double t_rr = block_reduce<false>(s_rr, lds);
+    const double t_rmax = block_reduce<true>(s_rmax, lds);
+    const double t_dmax = block_reduce<true>(s_dmax, lds);
+    const double t_d2 = block_reduce<false>(s_d2, lds);
+    double t_emax = 0, t_e2 = 0;
+    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce<false>(s_e2, lds); }
+    if (threadIdx.x == 0) {
+        const int b = blockIdx.x, st = a.strideB;
+        a.partB[FB_RR * st + b] = t_rr;     a.partB[FB_RMAX * st + b] = t_rmax;
+        a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
+        a.partB[FB_D2 * st + b] = t_d2;     a.partB[FB_E2 * st + b] = t_e2;
+        if (blockIdx.x == 0) {
+            CgState o = s;
+            if (!a.init) { o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz; }
+            *a.s_out = o;
+        }
+    }
+}
+
+// ---- end-of-chunk check: same decision as the next stencil prologue, without advancing -------------
+struct CheckArgs {
+    const double* partB; int nB, strideB;
+    const CgState* s_in;      // state written by the last update kernel
+    CgState* summary;         // device copy that the host reads
+    HistEntry* hist;
+    RuleParams rp;
+    int want_diag;
+};
+__global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
+    __shared__ double lds[kWaves];
+    const CgState s = *a.s_in;
+    if (s.done) { if (threadIdx.x == 0) *a.summary = s; return; }
+    const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, 1, lds);
+    if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, s, d);
+}
+
+// Reduce one kernel's partials into `nf` totals (distributed mode: feeds the all-gather).
+__global__ __launch_bounds__(kBlock) void k_reduce_parts(const double* part, int n, int stride, int nf,
+                                                        unsigned max_mask, double* out) {
+    __shared__ double lds[kWaves];
+    for (int f = 0; f < nf; ++f) {
+        const double v = ((max_mask >> f) & 1u) ? reduce_parts<true>(part + f * stride, n, lds)
+                                                : reduce_parts<false>(part + f * stride, n, lds);
+        if (threadIdx.x == 0) out[f] = v;
+    }
+}
+
+// ---- packed (reference order) <-> storage layout ---------------------------------------------------
+// Packed index i (relative to the first owned row) of the reference's unknown vector
+// (grid_system.cpp:84-111) <-> node (x, y) <-> storage offset.
+struct PackGeom { Geom g; long long pk_begin, pk_len, bottom_size; };
+
+__device__ inline long long packed_to_storage(const PackGeom& pg, long long i_global) {
+    const Geom& g = pg.g;
+    int x, y;
+    if (i_global < pg.bottom_size) { const int w = g.half - 1; y = (int)(i_global / w) + 1; x = (int)(i_global - (long long)(y - 1) * w) + g.half + 1; }
+    else { const long long j = i_global - pg.bottom_size; const int w = g.N - 1; y = (int)(j / w) + g.half + 1; x = (int)(j - (long long)(y - g.half - 1) * w) + 1; }
+    return row_off(g, y) - g.base0 + x;
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_unpack(const PackGeom pg, const double* __restrict__ packed, T* __restrict__ storage) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < pg.pk_len; i += stride)
+        storage[packed_to_storage(pg, pg.pk_begin + i)] = (T)packed[i];
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack(const PackGeom pg, const T* __restrict__ storage, double* __restrict__ packed) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < pg.pk_len; i += stride)
+        packed[i] = (double)storage[packed_to_storage(pg, pg.pk_begin + i)];
+}
+
+// out = a - b over the owned flat range (true residual A x - b; dirichlet_solver.cpp:156-158)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sub(long long begin, long long len, const T* a, const T* b, T* out) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride) out[i] = a[i] - b[i];
+}
+// partial sums of (b - ax)^2 over the owned range: the REL_2NORM diagnostic residual
+// (matrix_free_system.cpp:457-463).  One partial per block.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_resid2(long long begin, long long len, const T* b, const T* ax, double* part) {
+    __shared__ double lds[kWaves];
+    const long long stride = (long long)gridDim.x * kBlock;
+    double s = 0.0;
+    for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride) {
+        const double d = (double)(b[i] - ax[i]);
+        s += d * d;
+    }
+    const double t = block_reduce<false>(s, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+}  // namespace mi355cg

@@ -1,0 +1,568 @@
+// mi355cg.hip -- C ABI (include/mi355cg.h) over the HIP kernels in cg_kernels.h.
+// One context = one GPU = one slab of grid rows (the whole grid on a single GPU).
+// No CPU fallback: every compute entry point needs a working HIP device.
+#include "../../include/mi355cg.h"
+#include "cg_kernels.h"
+#include "grid_setup.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mi355cg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCK(expr)                                                                                  \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(MI355CG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+inline long long round_up(long long v, long long m) { return (v + m - 1) / m * m; }
+
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev.push_back(e); }
+        return ev[used++];
+    }
+    void reset() { used = 0; }
+    void destroy() { for (auto e : ev) hipEventDestroy(e); ev.clear(); used = 0; }
+};
+
+}  // namespace
+
+struct mi355cg_ctx {
+    int device = 0;
+    int dtype = MI355CG_F64;
+    hipStream_t stream = nullptr;
+    GridParams gp;
+    Geom g{};
+    long long storage_len = 0;          // elements per vector incl. ghost rows
+    long long pk_begin = 0, pk_len = 0; // owned packed range
+    WorkList wl{};
+    int grid_stencil = 0, grid_update = 0, rows_per_item = 0, depth = 4;
+    int strideA = 0, strideB = 0;
+
+    // device vectors in storage layout (fp64 set always; fp32 set for F32_MIXED)
+    double *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
+    float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr, *bf = nullptr;
+    double* packed = nullptr;           // device scratch, pk_len doubles
+    double *partA = nullptr, *partB = nullptr, *partR = nullptr;
+    CgState *sA = nullptr, *sB = nullptr, *summary = nullptr;
+    HistEntry* hist = nullptr;
+    CgState* summary_h = nullptr;       // pinned
+    HistEntry* hist_h = nullptr;        // pinned
+    double* partR_h = nullptr;          // pinned
+
+    std::vector<double> rhs_h, u_h;     // packed host copies (owned range)
+    bool have_u_dev = false, solved = false;
+    int cur = 0;                        // p[cur] holds the current direction after the last stencil
+
+    bool profiling = false;
+    EventPool events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[2];
+    double kernel_ms[2] = {0, 0};
+    long long kernel_launches[2] = {0, 0};
+};
+
+namespace {
+
+// ---- layout ----------------------------------------------------------------------------------------
+long long phys_start(const Geom& g, int y) { return row_off(g, y) + (y <= g.half ? g.cb : 0); }
+long long phys_end(const Geom& g, int y) { return phys_start(g, y) + (y <= g.half ? g.Pb : g.Pu); }
+
+void build_geom(mi355cg_ctx* c, int vec, int y_lo, int y_hi) {
+    Geom& g = c->g;
+    const GridParams& gp = c->gp;
+    g.N = gp.n; g.half = gp.half;
+    g.Pu = (int)round_up(g.N + 1, 32);
+    g.cb = g.half & ~31;
+    g.Pb = g.Pu - g.cb;
+    g.xlim = (int)round_up(g.N + 1, vec);
+    g.y_lo = y_lo; g.y_hi = y_hi;
+    g.base0 = 0;
+    g.base0 = phys_start(g, y_lo - 1);
+    c->storage_len = phys_end(g, y_hi + 1) - g.base0;
+    g.own_begin = phys_start(g, y_lo) - g.base0;
+    g.own_len = phys_end(g, y_hi) - phys_start(g, y_lo);
+    g.A = gp.A; g.xk = gp.x_k; g.yk = gp.y_k;
+    c->pk_begin = packed_row_begin(gp, y_lo);
+    c->pk_len = (y_hi + 1 <= gp.n - 1 ? packed_row_begin(gp, y_hi + 1) : gp.size) - c->pk_begin;
+}
+
+// Cut the owned rows into (chunk, strip) items: one wave marches `ty` rows of a 64*vec-column strip.
+void build_worklist(mi355cg_ctx* c, int vec) {
+    const Geom& g = c->g;
+    const int sw = kWave * vec;
+    WorkList& wl = c->wl;
+    wl.np = 0; wl.nitems = 0;
+    struct Rect { int y0, y1, s0, ns; } rects[2];
+    int nr = 0;
+    const int ns_all = (g.N - 1) / sw + 1;
+    if (g.y_lo <= g.half) {                                   // bottom-right block rows
+        const int s0 = (g.half + 1) / sw;
+        rects[nr++] = {std::max(g.y_lo, 1), std::min(g.y_hi, g.half), s0, ns_all - s0};
+    }
+    if (g.y_hi > g.half)                                      // upper block rows
+        rects[nr++] = {std::max(g.y_lo, g.half + 1), std::min(g.y_hi, g.N - 1), 0, ns_all};
+    long long strip_rows = 0;
+    for (int i = 0; i < nr; ++i) strip_rows += (long long)(rects[i].y1 - rects[i].y0 + 1) * rects[i].ns;
+    const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 2048));
+    int ty = (int)((strip_rows + target_waves - 1) / target_waves);
+    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), std::min(ty, 512));
+    if (env_int("MI355CG_ROWS", 0) > 0) ty = env_int("MI355CG_ROWS", 0);
+    c->rows_per_item = ty;
+    for (int i = 0; i < nr; ++i) {
+        const int rows = rects[i].y1 - rects[i].y0 + 1;
+        if (rows <= 0) continue;
+        Panel& P = wl.p[wl.np++];
+        P.y0 = rects[i].y0; P.y1 = rects[i].y1; P.s0 = rects[i].s0; P.ns = rects[i].ns;
+        P.nchunks = (rows + ty - 1) / ty;
+        P.ty = (rows + P.nchunks - 1) / P.nchunks;            // rebalance
+        P.nchunks = (rows + P.ty - 1) / P.ty;
+        P.item0 = wl.nitems;
+        wl.nitems += P.ns * P.nchunks;
+    }
+    const int max_blocks = std::max(1, env_int("MI355CG_STENCIL_BLOCKS", 1024));
+    c->grid_stencil = std::max(1, std::min(max_blocks, (wl.nitems + kWaves - 1) / kWaves));
+    const long long nvec = g.own_len / vec;
+    const int max_upd = std::max(1, env_int("MI355CG_UPDATE_BLOCKS", 1024));
+    c->grid_update = (int)std::max<long long>(1, std::min<long long>(max_upd, (nvec + kBlock - 1) / kBlock));
+    c->depth = env_int("MI355CG_DEPTH", 4);
+}
+
+PackGeom pack_geom(const mi355cg_ctx* c) {
+    PackGeom pg; pg.g = c->g; pg.pk_begin = c->pk_begin; pg.pk_len = c->pk_len; pg.bottom_size = c->gp.bottom_size;
+    return pg;
+}
+int flat_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>(2048, (n + kBlock - 1) / kBlock)); }
+
+// ---- launchers -------------------------------------------------------------------------------------
+template <typename T, int VEC, bool FUSED, bool MSG>
+void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a) {
+    dim3 grid(c->grid_stencil), block(kBlock);
+    switch (c->depth) {
+        case 2: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 2>), grid, block, 0, c->stream, a); break;
+        case 8: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 8>), grid, block, 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 4>), grid, block, 0, c->stream, a); break;
+    }
+}
+
+template <typename T, int VEC>
+StencilArgs<T> stencil_args_common(const mi355cg_ctx* c) {
+    StencilArgs<T> a{};
+    a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC);
+    a.wl = c->wl;
+    return a;
+}
+
+// y = A_h v (plain operator apply on storage-layout vectors)
+template <typename T, int VEC>
+void launch_apply(const mi355cg_ctx* c, const T* v, T* out) {
+    StencilArgs<T> a = stencil_args_common<T, VEC>(c);
+    a.pin = v; a.ap = out; a.partA = nullptr;
+    launch_stencil_depth<T, VEC, false, false>(c, a);
+}
+
+struct IterCfg { RuleParams rp; int want_diag; bool has_u; };
+
+template <typename T, int VEC>
+void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], T* ap) {
+    StencilArgs<T> a = stencil_args_common<T, VEC>(c);
+    a.r = r; a.pin = p[c->cur]; a.pout = p[c->cur ^ 1]; a.ap = ap;
+    a.partB = c->partB; a.nB = c->grid_update; a.strideB = c->strideB;
+    a.partA = c->partA; a.strideA = c->strideA;
+    a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
+    if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a);
+    else launch_stencil_depth<T, VEC, true, false>(c, a);
+    c->cur ^= 1;
+}
+
+template <typename T, int VEC>
+void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, bool init) {
+    UpdateArgs<T> a{};
+    a.begin = c->g.own_begin / VEC; a.nvec = c->g.own_len / VEC;
+    a.x = x; a.r = r; a.p = p; a.ap = ap; a.u = u;
+    a.partA = c->partA; a.nA = c->grid_stencil; a.strideA = c->strideA;
+    a.partB = c->partB; a.strideB = c->strideB;
+    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0;
+    dim3 grid(c->grid_update), block(kBlock);
+    if (cfg.has_u) hipLaunchKernelGGL((k_update<T, VEC, true>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_update<T, VEC, false>), grid, block, 0, c->stream, a);
+}
+
+void launch_check(mi355cg_ctx* c, const IterCfg& cfg) {
+    CheckArgs a{};
+    a.partB = c->partB; a.nB = c->grid_update; a.strideB = c->strideB;
+    a.s_in = c->sB; a.summary = c->summary; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, c->stream, a);
+}
+
+template <typename T>
+int upload_packed(mi355cg_ctx* c, const double* host_packed, T* storage) {
+    HIPCK(hipMemcpyAsync(c->packed, host_packed, sizeof(double) * c->pk_len, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL((k_unpack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), c->packed, storage);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(c->stream));
+    return MI355CG_OK;
+}
+template <typename T>
+int download_packed(mi355cg_ctx* c, const T* storage, double* host_packed) {
+    hipLaunchKernelGGL((k_pack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), storage, c->packed);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(host_packed, c->packed, sizeof(double) * c->pk_len, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return MI355CG_OK;
+}
+
+int alloc_vec(double** p, long long n) {
+    HIPCK(hipMalloc((void**)p, sizeof(double) * n));
+    HIPCK(hipMemset(*p, 0, sizeof(double) * n));
+    return MI355CG_OK;
+}
+
+int ensure_u_on_device(mi355cg_ctx* c) {
+    if (c->have_u_dev) return MI355CG_OK;
+    if (int rc = upload_packed<double>(c, c->u_h.data(), c->u)) return rc;
+    c->have_u_dev = true;
+    return MI355CG_OK;
+}
+
+void prof_begin(mi355cg_ctx* c, int k, hipEvent_t* e0) {
+    if (!c->profiling) return;
+    *e0 = c->events.get();
+    if (*e0) hipEventRecord(*e0, c->stream);
+    (void)k;
+}
+void prof_end(mi355cg_ctx* c, int k, hipEvent_t e0) {
+    if (!c->profiling || !e0) return;
+    hipEvent_t e1 = c->events.get();
+    if (!e1) return;
+    hipEventRecord(e1, c->stream);
+    c->ev_pairs[k].push_back({e0, e1});
+}
+void prof_collect(mi355cg_ctx* c) {
+    for (int k = 0; k < 2; ++k) {
+        double tot = 0; long long n = 0;
+        for (auto& pr : c->ev_pairs[k]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { tot += ms; ++n; }
+        }
+        c->kernel_ms[k] = n ? tot / n : 0.0;
+        c->kernel_launches[k] = n;
+        c->ev_pairs[k].clear();
+    }
+    c->events.reset();
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+const char* mi355cg_last_error(void) { return g_err.c_str(); }
+const char* mi355cg_version(void) { return "mi355cg 0.1 (gfx950)"; }
+
+int mi355cg_create(int n, int m, double a, double b, double c_, double d, int dtype, int device, mi355cg_handle* out) {
+    if (!out) return fail(MI355CG_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (dtype != MI355CG_F64 && dtype != MI355CG_F32_MIXED) return fail(MI355CG_ERR_INVALID, "unknown dtype %d", dtype);
+    GridParams gp;
+    if (!grid_params_init(&gp, n, m, a, b, c_, d))
+        return fail(MI355CG_ERR_INVALID, "grid %dx%d rejected: the L-shaped index map is only consistent for n == m, even, >= 6", n, m);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MI355CG_ERR_HIP, "no HIP device available (libmi355cg has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MI355CG_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    HIPCK(hipSetDevice(device));
+
+    mi355cg_ctx* c = new mi355cg_ctx();
+    c->device = device; c->dtype = dtype; c->gp = gp;
+    const int vec = 2;                      // fp64 layout; the fp32 kernels use VEC=4 on the same pitches
+    build_geom(c, vec, 1, gp.n - 1);
+    build_worklist(c, vec);
+    c->strideA = c->grid_stencil; c->strideB = c->grid_update;
+
+    int rc = MI355CG_OK;
+    auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "hipStreamCreate failed"); return cleanup(); }
+    const long long L = c->storage_len;
+    double** vecs[] = {&c->x, &c->r, &c->p[0], &c->p[1], &c->ap, &c->b, &c->u};
+    for (auto v : vecs) if ((rc = alloc_vec(v, L))) return cleanup();
+    if ((rc = alloc_vec(&c->packed, std::max<long long>(c->pk_len, 1)))) return cleanup();
+    if ((rc = alloc_vec(&c->partA, (long long)FA_COUNT * c->strideA))) return cleanup();
+    if ((rc = alloc_vec(&c->partB, (long long)FB_COUNT * c->strideB))) return cleanup();
+    if ((rc = alloc_vec(&c->partR, 2048))) return cleanup();
+    if (hipMalloc((void**)&c->sA, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->sB, sizeof(CgState)) != hipSuccess ||
+        hipMalloc((void**)&c->summary, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->hist, sizeof(HistEntry) * kHist) != hipSuccess ||
+        hipHostMalloc((void**)&c->summary_h, sizeof(CgState)) != hipSuccess || hipHostMalloc((void**)&c->hist_h, sizeof(HistEntry) * kHist) != hipSuccess ||
+        hipHostMalloc((void**)&c->partR_h, sizeof(double) * 2048) != hipSuccess) {
+        rc = fail(MI355CG_ERR_HIP, "state allocation failed"); return cleanup();
+    }
+    hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
+    hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
+
+    // problem data on the host in the reference's packed order, then into storage layout on the device
+    c->rhs_h.resize(c->pk_len); c->u_h.resize(c->pk_len);
+    grid_fill_rows(gp, c->g.y_lo, c->g.y_hi, c->rhs_h.data(), c->u_h.data(), nullptr, nullptr);
+    if ((rc = upload_packed<double>(c, c->rhs_h.data(), c->b))) return cleanup();
+    *out = c;
+    return MI355CG_OK;
+}
+
+void mi355cg_destroy(mi355cg_handle c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->xf, c->rf, c->pf[0], c->pf[1], c->apf, c->bf,
+                   c->packed, c->partA, c->partB, c->partR, c->sA, c->sB, c->summary, c->hist};
+    for (void* p : dev) if (p) hipFree(p);
+    if (c->summary_h) hipHostFree(c->summary_h);
+    if (c->hist_h) hipHostFree(c->hist_h);
+    if (c->partR_h) hipHostFree(c->partR_h);
+    c->events.destroy();
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+long long mi355cg_size(mi355cg_handle c) { return c ? c->gp.size : -1; }
+
+int mi355cg_get_rhs(mi355cg_handle c, double* out) {
+    if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
+    std::memcpy(out, c->rhs_h.data(), sizeof(double) * c->pk_len);
+    return MI355CG_OK;
+}
+int mi355cg_get_true_solution(mi355cg_handle c, double* out) {
+    if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
+    std::memcpy(out, c->u_h.data(), sizeof(double) * c->pk_len);
+    return MI355CG_OK;
+}
+int mi355cg_get_node_coords(mi355cg_handle c, double* xs, double* ys) {
+    if (!c || !xs || !ys) return fail(MI355CG_ERR_INVALID, "null argument");
+    grid_fill_rows(c->gp, c->g.y_lo, c->g.y_hi, nullptr, nullptr, xs, ys);
+    return MI355CG_OK;
+}
+int mi355cg_set_rhs(mi355cg_handle c, const double* b) {
+    if (!c || !b) return fail(MI355CG_ERR_INVALID, "null argument");
+    HIPCK(hipSetDevice(c->device));
+    std::memcpy(c->rhs_h.data(), b, sizeof(double) * c->pk_len);
+    return upload_packed<double>(c, c->rhs_h.data(), c->b);
+}
+
+int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
+    if (!c || !x_dev || !y_dev) return fail(MI355CG_ERR_INVALID, "null argument");
+    HIPCK(hipSetDevice(c->device));
+    // p[1] <- unpack(x); ap <- A p[1]; y <- pack(ap).  (Scratch use only outside a solve.)
+    hipLaunchKernelGGL((k_unpack<double>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), x_dev, c->p[1]);
+    launch_apply<double, 2>(c, c->p[1], c->ap);
+    hipLaunchKernelGGL((k_pack<double>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), c->ap, y_dev);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(c->stream));
+    return MI355CG_OK;
+}
+
+int mi355cg_apply(mi355cg_handle c, const double* x, double* y) {
+    if (!c || !x || !y) return fail(MI355CG_ERR_INVALID, "null argument");
+    HIPCK(hipSetDevice(c->device));
+    if (int rc = upload_packed<double>(c, x, c->p[1])) return rc;
+    launch_apply<double, 2>(c, c->p[1], c->ap);
+    HIPCK(hipGetLastError());
+    return download_packed<double>(c, c->ap, y);
+}
+
+void mi355cg_default_params(mi355cg_params* p, int rule) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->rule = rule;
+    p->max_iterations = 10000;                 // solver.hpp:36, matrix_free_system.hpp:101
+    p->eps_precision = 1e-6; p->eps_residual = 1e-6; p->eps_exact_error = 1e-6;   // msg_solver.hpp:52-56
+    p->eps_rel = 1e-6;                         // matrix_free_system.hpp:100
+    p->use_true_solution = 1;
+    p->callback_every = rule == MI355CG_RULE_MSG_MAXNORM ? 100 : 1;
+    p->diagnostics = 0;
+    p->sync_every = 0;
+    p->fixed_iterations = 0;
+}
+
+int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
+                  const volatile int* stop_flag, mi355cg_results* out) {
+    if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (prm->rule != MI355CG_RULE_MSG_MAXNORM && prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "unknown rule %d", prm->rule);
+    if (c->dtype != MI355CG_F64) return fail(MI355CG_ERR_INVALID, "F32_MIXED solve is not wired in this build yet");
+    HIPCK(hipSetDevice(c->device));
+    const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
+    IterCfg cfg{};
+    cfg.rp.rule = prm->rule; cfg.rp.max_iterations = prm->max_iterations;
+    cfg.rp.eps_precision = prm->eps_precision; cfg.rp.eps_residual = prm->eps_residual;
+    cfg.rp.eps_exact_error = prm->eps_exact_error; cfg.rp.eps_rel = prm->eps_rel;
+    cfg.rp.fixed_iterations = prm->fixed_iterations;
+    const bool diag = !msg && prm->diagnostics;
+    cfg.has_u = (msg && prm->use_true_solution) || diag;
+    cfg.rp.use_u = cfg.has_u ? 1 : 0;
+    cfg.want_diag = diag ? 1 : 0;
+    if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
+
+    const auto t0 = std::chrono::steady_clock::now();
+    c->events.reset(); c->ev_pairs[0].clear(); c->ev_pairs[1].clear();
+
+    // x = 0, r = b, z = 0 (the first stencil makes z = r + 0*z = r), A z = 0    msg_solver.cpp:33-39
+    const size_t bytes = sizeof(double) * c->storage_len;
+    HIPCK(hipMemsetAsync(c->x, 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->p[0], 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->p[1], 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->ap, 0, bytes, c->stream));
+    HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
+    c->cur = 0;
+    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, /*init=*/true);
+    HIPCK(hipGetLastError());
+
+    auto poll = [&]() -> int {
+        launch_check(c, cfg);
+        HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipMemcpyAsync(c->hist_h, c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        return MI355CG_OK;
+    };
+    if (int rc = poll()) return rc;
+    const double initial_rnorm2 = c->summary_h->rnorm2;
+    if (msg && cb) cb(user, 0, DBL_MAX, c->summary_h->rmax, cfg.has_u ? c->summary_h->emax : DBL_MAX);   // msg_solver.cpp:75-77
+
+    int sync_every = prm->sync_every > 0 ? prm->sync_every : (diag ? 1 : (msg ? 100 : 200));
+    sync_every = std::min(sync_every, kHist);
+    const int every = prm->callback_every;
+    int it_done = 0;
+    bool interrupted = false;
+    while (!c->summary_h->done) {
+        if (stop_flag && *stop_flag) { interrupted = true; break; }            // msg_solver.cpp:82-87
+        int m = std::min(sync_every, prm->max_iterations - it_done);
+        if (msg && every > 0) m = std::min(m, every - it_done % every);        // land on the callback iterations
+        if (m <= 0) m = 1;                                                    // lets the kernels record ITERATIONS
+        for (int k = 0; k < m; ++k) {
+            hipEvent_t e0 = nullptr;
+            prof_begin(c, 0, &e0);
+            launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap);
+            prof_end(c, 0, e0);
+            prof_begin(c, 1, &e0);
+            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false);
+            prof_end(c, 1, e0);
+            if (diag) {
+                // MatrixFreeSolver's per-iteration report: second apply for the TRUE residual
+                // (matrix_free_system.cpp:457-468).  One iteration per poll in this mode.
+                launch_apply<double, 2>(c, c->x, c->p[c->cur ^ 1]);            // scratch: the inactive direction buffer
+                hipLaunchKernelGGL((k_resid2<double>), dim3(1024), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->p[c->cur ^ 1], c->partR);
+                HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * 1024, hipMemcpyDeviceToHost, c->stream));
+            }
+        }
+        HIPCK(hipGetLastError());
+        if (int rc = poll()) return rc;
+        const int it_now = c->summary_h->it;
+        if (diag) {
+            // the stencil that follows would overwrite the scratch anyway: it holds A x, not a direction
+            if (it_now > it_done) {
+                double s = 0; for (int i = 0; i < 1024; ++i) s += c->partR_h[i];
+                const HistEntry& h = c->hist_h[it_now % kHist];
+                if (cb) cb(user, it_now - 1, std::sqrt(h.d2), std::sqrt(s), std::sqrt(h.e2));
+            }
+            // restore the zero-ness contract of the scratch direction buffer's ghost/pad cells: A x is
+            // masked to interior nodes by the kernel, pads stay 0, and the next stencil rewrites it.
+        } else if (msg && cb) {
+            for (int it = it_done + 1; it <= it_now; ++it) {
+                // callbacks only on iterations that did NOT stop (msg_solver.cpp:172-183 sits after the breaks)
+                const bool stopped_here = c->summary_h->done && c->summary_h->reason != MI355CG_STOP_ITERATIONS && it == it_now;
+                if ((it == 1 || (every > 0 && it % every == 0)) && !stopped_here) {
+                    const HistEntry& h = c->hist_h[it % kHist];
+                    cb(user, it, h.dmax, h.rmax, cfg.has_u ? h.emax : DBL_MAX);
+                }
+            }
+        }
+        it_done = it_now;
+    }
+    const CgState fin = *c->summary_h;
+    c->solved = true;
+    prof_collect(c);
+    mi355cg_results res{};
+    res.iterations = fin.it;
+    res.converged = interrupted ? 0 : fin.converged;
+    res.stop_reason = interrupted ? MI355CG_STOP_INTERRUPTED : fin.reason;
+    res.final_residual_norm = fin.rmax;
+    res.final_precision = fin.it > 0 ? fin.dmax : DBL_MAX;
+    res.final_error_norm = cfg.has_u ? fin.emax : DBL_MAX;
+    res.r_norm2 = fin.rnorm2;
+    res.initial_r_norm2 = initial_rnorm2;
+    res.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (msg && cb) cb(user, res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm);   // msg_solver.cpp:193-195
+    if (out) *out = res;
+    return MI355CG_OK;
+}
+
+int mi355cg_get_solution(mi355cg_handle c, double* x) {
+    if (!c || !x) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (!c->solved) return fail(MI355CG_ERR_STATE, "no solve has run on this handle");
+    HIPCK(hipSetDevice(c->device));
+    return download_packed<double>(c, c->x, x);
+}
+int mi355cg_get_recursive_residual(mi355cg_handle c, double* r) {
+    if (!c || !r) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (!c->solved) return fail(MI355CG_ERR_STATE, "no solve has run on this handle");
+    HIPCK(hipSetDevice(c->device));
+    return download_packed<double>(c, c->r, r);
+}
+int mi355cg_get_true_residual(mi355cg_handle c, double* out) {
+    if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (!c->solved) return fail(MI355CG_ERR_STATE, "no solve has run on this handle");
+    HIPCK(hipSetDevice(c->device));
+    // residual = A x - b   (dirichlet_solver.cpp:147-161); scratch: A x in ap, difference in the inactive direction buffer
+    launch_apply<double, 2>(c, c->x, c->ap);
+    double* scratch = c->p[c->cur ^ 1];
+    hipLaunchKernelGGL((k_sub<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->ap, c->b, scratch);
+    HIPCK(hipGetLastError());
+    return download_packed<double>(c, scratch, out);
+}
+
+int mi355cg_set_profiling(mi355cg_handle c, int enable) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    c->profiling = enable != 0;
+    return MI355CG_OK;
+}
+int mi355cg_get_kernel_time(mi355cg_handle c, int kernel, double* avg_ms, long long* launches) {
+    if (!c || kernel < 0 || kernel > 1) return fail(MI355CG_ERR_INVALID, "bad argument");
+    if (avg_ms) *avg_ms = c->kernel_ms[kernel];
+    if (launches) *launches = c->kernel_launches[kernel];
+    return MI355CG_OK;
+}
+int mi355cg_get_layout(mi355cg_handle c, long long* padded_len, int* pitch_bottom, int* pitch_upper,
+                       int* grid_stencil, int* grid_update, int* rows_per_item) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    if (padded_len) *padded_len = c->g.own_len;
+    if (pitch_bottom) *pitch_bottom = c->g.Pb;
+    if (pitch_upper) *pitch_upper = c->g.Pu;
+    if (grid_stencil) *grid_stencil = c->grid_stencil;
+    if (grid_update) *grid_update = c->grid_update;
+    if (rows_per_item) *rows_per_item = c->rows_per_item;
+    return MI355CG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+"""GPU parity tests: the HIP path (through the C ABI, libmi355cg.so) against the CPU oracle on
+the same inputs, against the committed golden fixture, and -- at BASELINE's full size -- through
+size-independent properties.
+
+Bars: bit-exact for everything the reference computes element-wise (RHS, exact solution,
+stencil apply, packed index map); for CG, identical iteration counts / stop reasons and residual
+norms within 1e-12 relative to ||b||_2 (north_star's tolerance; the only arithmetic that differs
+from the oracle is the summation order of the inner products).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-12          # | ||r||_gpu - ||r||_oracle | / ||b||_2
+
+
+@pytest.fixture(scope="module")
+def isa():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import iterative_solvers_amd as isa
+    isa.load()
+    return isa
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    return o
+
+
+SIZES_SMALL = [6, 8, 10, 16, 30, 64, 66, 130, 256, 258]
+
+
+@pytest.mark.parametrize("N", SIZES_SMALL)
+def test_setup_vectors_bit_exact(isa, oracle, N):
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N, 1.0, 2.0, 1.0, 2.0)
+    assert s.size() == og.size == (N // 2 - 1) * (3 * N // 2 - 1)
+    assert np.array_equal(s.get_rhs(), og.rhs())
+    assert np.array_equal(s.get_true_solution_vector(), og.true_solution())
+    xs, ys = og.node_coords()
+    assert np.array_equal(s.get_x_coords(), xs) and np.array_equal(s.get_y_coords(), ys)
+    assert s.get_node_coordinates(0) == (xs[0], ys[0])
+    assert s.get_node_coordinates(-1) == (0.0, 0.0) and s.get_node_coordinates(s.size()) == (0.0, 0.0)
+
+
+@pytest.mark.parametrize("N", SIZES_SMALL + [1024])
+def test_apply_bit_exact_seeded(isa, oracle, N):
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N, 1.0, 2.0, 1.0, 2.0)
+    rng = np.random.default_rng(12345)
+    for _ in range(2):
+        x = rng.uniform(-1.0, 1.0, s.size())
+        assert np.array_equal(s.apply(x), og.apply(x))
+    assert np.array_equal(s * np.ones(s.size()), og.apply(np.ones(s.size())))
+
+
+def test_apply_other_domain(isa, oracle):
+    s = isa.MatrixFreeSystem(32, 32, 0.0, 1.0, -1.0, 3.0)     # x_k != y_k
+    og = oracle.OracleGrid(32, 32, 0.0, 1.0, -1.0, 3.0)
+    x = np.random.default_rng(7).standard_normal(s.size())
+    assert np.array_equal(s.apply(x), og.apply(x))
+    assert np.array_equal(s.get_rhs(), og.rhs())
+
+
+def test_operator_equals_check_py_matrix(isa, golden_n6):
+    s = isa.MatrixFreeSystem(6, 6, 1.0, 2.0, 1.0, 2.0)
+    A = np.array(golden_n6["A"])
+    for j in range(16):
+        e = np.zeros(16)
+        e[j] = 1.0
+        assert np.array_equal(s.apply(e), A[:, j])
+
+
+def test_golden_two_iteration_trace(isa, golden_n6):
+    """py_debug.txt through the GPU path: 8-decimal b of check_debug.py, two CG iterations."""
+    s = isa.MatrixFreeSystem(6, 6, 1.0, 2.0, 1.0, 2.0)
+    b = np.array(golden_n6["b_check_debug"])
+    t = golden_n6["trace"]
+    for k, key in ((1, "x1"), (2, "x2")):
+        m = isa.MSGSolver(s, b, 1e-6, k)
+        m.setPrecisionEps(-1.0); m.setResidualEps(-1.0); m.setExactErrorEps(-1.0)
+        x = m.solve(None)
+        assert m.getIterations() == k and not m.hasConverged() and m.getStopReason() == isa.StopCriterion.ITERATIONS
+        assert np.allclose(x, t[key], rtol=1e-11, atol=1e-14)
+    r = s._handle.recursive_residual()
+    assert np.allclose(-r, t["r2"], rtol=1e-9, atol=1e-10)          # script keeps r = A x - b
+    mf = isa.MatrixFreeSolver(s, b, 0.0, 2)
+    assert np.allclose(mf.solve(), t["x2"], rtol=1e-11, atol=1e-14)
+
+
+@pytest.mark.parametrize("N", [6, 16, 64, 256])
+def test_cg_rel2norm_matches_oracle(isa, oracle, N):
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N, 1.0, 2.0, 1.0, 2.0)
+    ref = og.mf_solve(eps=1e-8, max_iterations=10 ** 6)
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+    done = []
+    sol.setCompletionCallback(lambda ok, msg: done.append((ok, msg)))
+    x = sol.solve()
+    assert sol.getIterations() == ref.iterations
+    assert done == [(True, "Converged successfully")]
+    res = sol.last_results
+    assert res.initial_r_norm2 == pytest.approx(ref.initial_r_norm, rel=1e-14)
+    assert abs(res.r_norm2 - ref.r_norm) / ref.initial_r_norm <= REL_TOL
+    assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+    b = og.rhs()
+    true_gpu = np.linalg.norm(b - og.apply(x))
+    true_ref = np.linalg.norm(b - og.apply(ref.x))
+    assert abs(true_gpu - true_ref) / ref.initial_r_norm <= REL_TOL
+
+
+def test_n256_reference_run(isa, oracle):
+    """the reference's own MatrixFreeSolver needs 701 iterations at N=256."""
+    s = isa.MatrixFreeSystem(256, 256, 1.0, 2.0, 1.0, 2.0)
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+    x = sol.solve()
+    assert sol.getIterations() == 701
+    og = oracle.OracleGrid(256, 256)
+    assert np.linalg.norm(og.rhs() - og.apply(x)) == pytest.approx(1.225611e-01, rel=1e-4)
+
+
+@pytest.mark.parametrize("N", [16, 64])
+def test_cg_diagnostics_callback_trace(isa, oracle, N):
+    """Per-iteration (precision, TRUE residual, error) 2-norms of MatrixFreeSolver's callback."""
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N, 1.0, 2.0, 1.0, 2.0)
+    ref = og.mf_solve(eps=1e-8, max_iterations=10 ** 6, diagnostics=True)
+    got = []
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+    sol.setIterationCallback(lambda it, p, r, e: got.append((it, p, r, e)))
+    x = sol.solve(s.get_true_solution_vector())
+    assert [g[0] for g in got] == [c[0] for c in ref.callbacks]
+    g, c = np.array(got), np.array(ref.callbacks)
+    assert np.abs(g[:, 2] - c[:, 2]).max() / ref.initial_r_norm <= REL_TOL       # true residual
+    assert np.allclose(g[:, 1], c[:, 1], rtol=1e-8, atol=1e-13)                   # ||dx||_2
+    assert np.allclose(g[:, 3], c[:, 3], rtol=1e-8, atol=1e-13)                   # ||x-u||_2
+    assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+
+
+def _msg_compare(isa, og, s, **eps):
+    ref = og.msg_solve(**eps)
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-6, eps.get("max_iterations", 10000))
+    m.setPrecisionEps(eps.get("eps_precision", 1e-6))
+    m.setResidualEps(eps.get("eps_residual", 1e-6))
+    m.setExactErrorEps(eps.get("eps_exact_error", -1.0))
+    got = []
+    m.setIterationCallback(lambda it, p, r, e: got.append((it, p, r, e)))
+    x = m.solve(s.get_true_solution_vector())
+    return ref, m, x, got
+
+
+@pytest.mark.parametrize("N", [6, 16, 64, 256])
+def test_msg_defaults_match_oracle(isa, oracle, N):
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N, 1.0, 2.0, 1.0, 2.0)
+    ref, m, x, got = _msg_compare(isa, og, s)
+    assert (m.getIterations(), int(m.getStopReason()), m.hasConverged()) == (ref.iterations, ref.stop_reason, ref.converged)
+    assert [g[0] for g in got] == [c[0] for c in ref.callbacks]
+    g, c = np.array(got), np.array(ref.callbacks)
+    assert g[0, 1] == c[0, 1]                                   # DBL_MAX at iteration 0
+    b2 = ref.initial_r_norm2
+    assert np.abs(g[:, 2] - c[:, 2]).max() / b2 <= REL_TOL       # ||r||_inf history
+    assert np.allclose(g[1:, 1], c[1:, 1], rtol=1e-7, atol=1e-14)
+    assert np.allclose(g[:, 3], c[:, 3], rtol=1e-9, atol=1e-14)
+    assert abs(m.getFinalResidualNorm() - ref.final_residual_norm) / b2 <= REL_TOL
+    assert m.getFinalErrorNorm() == pytest.approx(ref.final_error_norm, rel=1e-9)
+    assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+    assert m.getStopReasonText() != ""
+
+
+def test_msg_n256_known_counts(isa, oracle):
+    s = isa.GridSystem(256, 256, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(256, 256)
+    ref, m, x, got = _msg_compare(isa, og, s, eps_precision=-1.0, eps_residual=1e-8)
+    assert (m.getIterations(), m.getStopReason()) == (1004, isa.StopCriterion.RESIDUAL) == (ref.iterations, ref.stop_reason)
+    assert m.getFinalResidualNorm() < 1e-8
+    ref, m, x, got = _msg_compare(isa, og, s, eps_precision=1e-8, eps_residual=1e-8, eps_exact_error=1e-8)
+    assert (m.getIterations(), m.getStopReason()) == (757, isa.StopCriterion.PRECISION)
+
+
+def test_msg_error_criterion_and_no_true_solution(isa, oracle):
+    N = 32
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    ref, m, x, got = _msg_compare(isa, og, s, eps_precision=-1.0, eps_residual=-1.0, eps_exact_error=1e-3)
+    assert (m.getIterations(), int(m.getStopReason())) == (ref.iterations, ref.stop_reason)
+    assert m.getStopReason() == isa.StopCriterion.EXACT_ERROR
+    # extent-0 true solution: error norm stays DBL_MAX, error criterion can never fire
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-6, 50)
+    m.setPrecisionEps(-1.0); m.setResidualEps(-1.0); m.setExactErrorEps(1e30)
+    got = []
+    m.setIterationCallback(lambda it, p, r, e: got.append(e))
+    m.solve(None)
+    assert m.getIterations() == 50 and not m.hasConverged()
+    assert all(e == np.finfo(np.float64).max for e in got)
+    ref = og.msg_solve(true_solution=None, eps_precision=-1.0, eps_residual=-1.0, eps_exact_error=1e30, max_iterations=50)
+    assert abs(m.getFinalResidualNorm() - ref.final_residual_norm) / ref.initial_r_norm2 <= REL_TOL
+
+
+def test_iteration_caps_and_zero_iterations(isa):
+    s = isa.GridSystem(16, 16, 1.0, 2.0, 1.0, 2.0)
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-30, 0)
+    x = m.solve(s.get_true_solution_vector())
+    assert m.getIterations() == 0 and not m.hasConverged() and np.all(x == 0.0)
+    mf = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-30, 3)
+    msgs = []
+    mf.setCompletionCallback(lambda ok, msg: msgs.append((ok, msg)))
+    mf.solve()
+    assert mf.getIterations() == 3 and msgs == [(False, "Failed to converge within maximum iterations")]
+
+
+def test_stop_request_interrupts(isa):
+    s = isa.GridSystem(128, 128, 1.0, 2.0, 1.0, 2.0)
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-30, 100000)
+    m.setPrecisionEps(-1.0); m.setResidualEps(-1.0); m.setExactErrorEps(-1.0)
+    m.setIterationCallback(lambda it, p, r, e: m.requestStop() if it == 200 else None)
+    m.solve(s.get_true_solution_vector())
+    assert m.getStopReason() == isa.StopCriterion.INTERRUPTED and not m.hasConverged()
+    assert m.getIterations() == 200 and m.isStopRequested()
+
+
+def test_dirichlet_solver_facade(isa, oracle):
+    N = 64
+    d = isa.DirichletSolver(N, N, 1.0, 2.0, 1.0, 2.0)
+    d.setSolverParameters(1e-8, 1e-8, 1e-8, 100000)
+    its = []
+    d.setIterationCallback(lambda it, p, r, e: its.append(it))
+    fin = []
+    d.setCompletionCallback(lambda res: fin.append(res.iterations))
+    res = d.solve()
+    og = oracle.OracleGrid(N, N)
+    ref = og.msg_solve(eps_precision=1e-8, eps_residual=1e-8, eps_exact_error=-1.0, max_iterations=100000)
+    assert res.iterations == ref.iterations and res.converged and fin == [res.iterations]
+    assert its[0] == 0 and its[1] == 1 and its[-1] == res.iterations
+    assert np.array_equal(res.residual, og.apply(res.solution) - og.rhs())      # A x - b with the bit-exact operator
+    assert np.array_equal(res.error, res.solution - res.true_solution)
+    assert res.error_norm == pytest.approx(np.abs(res.error).max(), rel=1e-12)
+    assert res.stop_reason == d.solver.getStopReasonText()
+    assert len(res.x_coords) == len(res.solution) == og.size
+
+
+@pytest.mark.parametrize("n,m", [(7, 7), (8, 6), (6, 8), (4, 4), (9, 9)])
+def test_invalid_grids_rejected(isa, n, m):
+    with pytest.raises(ValueError):
+        isa.GridSystem(m, n, 1.0, 2.0, 1.0, 2.0)
+
+
+def test_errors_are_loud(isa):
+    s = isa.MatrixFreeSystem(8, 8, 1.0, 2.0, 1.0, 2.0)
+    with pytest.raises(ValueError):
+        s.apply(np.zeros(5))
+    with pytest.raises(isa.Mi355cgError):
+        s._handle.solution()                                     # no solve yet
+
+
+def test_full_size_4096_apply_and_cg_properties(isa, oracle):
+    """BASELINE config 2 size.  Stencil bit-exact against the oracle; 25 CG iterations compared
+    with the oracle's; recursive residual consistent with the true residual."""
+    N = 4096
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    assert s.size() == 12574721
+    b = og.rhs()
+    assert np.array_equal(s.get_rhs(), b)
+    x = np.random.default_rng(12345).uniform(-1.0, 1.0, s.size())
+    assert np.array_equal(s.apply(x), og.apply(x))
+    k = 25
+    m = isa.MSGSolver(s, b, 1e-30, k)
+    m.setPrecisionEps(-1.0); m.setResidualEps(-1.0); m.setExactErrorEps(-1.0)
+    xg = m.solve(s.get_true_solution_vector())
+    ref = og.msg_solve(eps_precision=-1.0, eps_residual=-1.0, eps_exact_error=-1.0, max_iterations=k)
+    assert m.getIterations() == k == ref.iterations
+    b2 = ref.initial_r_norm2
+    assert abs(m.getFinalResidualNorm() - ref.final_residual_norm) / b2 <= REL_TOL
+    assert abs(m.last_results.r_norm2 - ref.r_norm2) / b2 <= REL_TOL
+    assert np.abs(xg - ref.x).max() <= 1e-11 * np.abs(ref.x).max()
+    rg = s._handle.recursive_residual()
+    assert np.abs(rg - (b - og.apply(xg))).max() <= 1e-9 * np.abs(b).max()
+
+
+def test_fixed_iteration_mode_ignores_convergence(isa):
+    s = isa.MatrixFreeSystem(16, 16, 1.0, 2.0, 1.0, 2.0)
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-2, 40)
+    sol.solve(fixed_iterations=True)
+    assert sol.getIterations() == 40
