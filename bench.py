@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/second and achieved HBM GB/s of the matrix-free CG hot path.
+
+A "step" is one CG iteration (fused stencil kernel A' + fused update kernel B) on the
+BASELINE config-2 workload: N x N = 4096 x 4096 intervals on the L-shaped domain, fp64,
+U = 12 574 721 unknowns per GPU, deterministic synthetic RHS (the reference's f and Dirichlet
+data), x0 = 0, convergence tests disabled so that exactly K iterations are timed.
+
+  python bench.py --gpus 1 --steps 2000 --warmup 200
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (weak scaling:
+      every rank owns a 4096-interval-class slab; the global grid grows with N)
+
+Prints ONE JSON line (rank 0).  value = total CG iterations/s of the job; hbm_gbps uses the
+ALGORITHMIC bytes of SURVEY 8d (88 B per unknown per iteration, fp64).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured-achievable
+ALG_BYTES_PER_UNKNOWN = 88.0    # 11 words fp64 per unknown per iteration
+KERNEL_ALG_WORDS = {"stencil": 4, "update": 6}   # fused A' = A+C with p ping-pong: read r,p write p,Ap; B: read x,p,r,Ap write x,r
+
+
+def unknowns(n: int) -> int:
+    return (n // 2 - 1) * (3 * n // 2 - 1)
+
+
+def cpu_baseline(n: int, iters: int):
+    """Time the CPU oracle (a port of the reference's MatrixFreeSolver loop, 1 thread) on a bounded
+    sample of the same workload."""
+    from oracle.oracle import OracleGrid
+    g = OracleGrid(n, n, 1.0, 2.0, 1.0, 2.0)
+    b = g.rhs()
+    u = g.true_solution()
+    t0 = time.perf_counter()
+    r = g.mf_solve(b=b, true_solution=u, eps=0.0, max_iterations=iters, diagnostics=False)
+    dt = time.perf_counter() - t0
+    assert r.iterations == iters
+    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} CG iterations of oracle/cg_oracle.c (MatrixFreeSolver loop without the "
+                      f"diagnostic second apply) at N={n}, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def read_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--n", type=int, default=4096, help="grid intervals per side on one GPU")
+    ap.add_argument("--rule", choices=["rel2", "msg"], default="rel2")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd import _capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    rule = _capi.RULE_REL_2NORM if args.rule == "rel2" else _capi.RULE_MSG_MAXNORM
+
+    if world > 1 or args.gpus > 1:
+        from iterative_solvers_amd import distributed as dist_cg
+        out = dist_cg.bench(args, rule)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+
+    n = args.n
+    U = unknowns(n)
+    sysm = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=local_rank)
+    h = sysm._handle
+
+    def run(iters: int, profile: bool):
+        p = isa.default_params(rule)
+        p.max_iterations = iters
+        p.fixed_iterations = 1
+        p.use_true_solution = 0
+        p.callback_every = 0
+        p.sync_every = 500
+        h.set_profiling(profile)
+        return h.solve(p)
+
+    run(args.warmup, False)                                   # untimed warm-up iterations
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run(args.steps, False)                              # exactly K iterations (plus the init pass)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert res.iterations == args.steps, (res.iterations, args.steps)
+    its = args.steps / dt
+
+    roofline = None
+    if not args.no_roofline_pass:
+        # same loop again with a HIP-event pair around every launch on the solve stream
+        k = min(args.steps, 500)
+        run(k, True)
+        t = {name: h.kernel_time(i) for i, name in enumerate(("stencil", "update"))}
+        dom = max(t, key=lambda name: t[name][0] * t[name][1])
+        ms, launches = t[dom]
+        alg = KERNEL_ALG_WORDS[dom] * 8.0 * U
+        achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tr = read_traffic()
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
+                    "alg_bytes_per_launch": alg,
+                    "other": {name: {"avg_ms": round(t[name][0], 5),
+                                     "achieved": round(KERNEL_ALG_WORDS[name] * 8.0 * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}
+                              for name in t}}
+
+    out = {
+        "metric": "cg_iters_per_sec", "value": round(its, 2), "unit": "iters/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson fp64, matrix-free CG, fixed {args.steps} iterations",
+                   "n": n, "unknowns": U, "rule": args.rule, "layout": h.layout()},
+        "hbm_gbps": round(ALG_BYTES_PER_UNKNOWN * U * its / 1e9, 1),
+        "hbm_frac_of_8TBps": round(ALG_BYTES_PER_UNKNOWN * U * its / 1e9 / HBM_PEAK_GBPS, 4),
+        "roofline": roofline,
+    }
+    if args.cpu_iters > 0:
+        out["cpu_baseline"] = cpu_baseline(n, args.cpu_iters)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -185,7 +185,29 @@ struct StencilArgs {
 
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
 
-template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH>
+// Work-item decode shared by the stencil and the 2-D update kernel.
+struct Item { int strip, ya, yb; };
+__device__ inline Item decode_item(const WorkList& wl, int item) {
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxPanels; ++k) if (k < wl.np && item >= wl.p[k].item0) pi = k;
+    const Panel P = wl.p[pi];
+    const int local = item - P.item0;
+    const int chunk = local / P.ns;
+    Item it;
+    it.strip = P.s0 + (local - chunk * P.ns);
+    it.ya = P.y0 + chunk * P.ty;
+    it.yb = min(P.y1, it.ya + P.ty - 1);
+    return it;
+}
+
+// One wave marches a (64*VEC)-column strip over rows ya..yb, ascending (DESC=false) or
+// descending (DESC=true), keeping three converted rows in registers and DEPTH raw rows in
+// flight.  In-row neighbours come from the adjacent lane (wave shuffle); the two wave-edge
+// lanes load their outside neighbour themselves.  The update kernel marches the same chunks
+// in the opposite direction, so each kernel starts on the rows the previous one touched last
+// (they are still in the 256 MiB Infinity Cache when the vectors are ~100 MB each).
+template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool DESC>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     typedef typename VecOf<T, VEC>::type vec_t;
     __shared__ double lds[kWaves];
@@ -205,23 +227,18 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
 
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     double acc_pap = 0.0, acc_rz = 0.0;
+    constexpr int DIR = DESC ? -1 : 1;
 
     struct Raw { vec_t r, p; T re, pe; };
 
     for (int item = blockIdx.x * kWaves + wave; item < a.wl.nitems; item += gridDim.x * kWaves) {
-        int pi = 0;
-#pragma unroll
-        for (int k = 1; k < kMaxPanels; ++k) if (k < a.wl.np && item >= a.wl.p[k].item0) pi = k;
-        const Panel P = a.wl.p[pi];
-        const int local = item - P.item0;
-        const int chunk = local / P.ns;
-        const int strip = P.s0 + (local - chunk * P.ns);
-        const int ya = P.y0 + chunk * P.ty;
-        const int yb = min(P.y1, ya + P.ty - 1);
-        const int x = strip * (kWave * VEC) + lane * VEC;
+        const Item it = decode_item(a.wl, item);
+        const int x = it.strip * (kWave * VEC) + lane * VEC;
         const bool xin = x < g.xlim;
         const bool edge = (lane == 0) || (lane == kWave - 1);
         const int xe = lane == 0 ? x - 1 : x + VEC;
+        const int nrows = it.yb - it.ya + 1;
+        const int ystart = DESC ? it.yb : it.ya;
 
         auto fetch = [&](int y, bool with_edge) -> Raw {
             Raw w;
@@ -241,35 +258,36 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         auto conv = [&](const Raw& w, vec_t& pn, T& pne) {
             if (FUSED) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) pn[j] = w.r[j] + beta * w.p[j];
+                for (int j = 0; j < VEC; ++j) pn[j] = w.r[j] + beta * w.p[j];     // z = r + beta*z
                 pne = w.re + beta * w.pe;
             } else { pn = w.p; pne = w.pe; }
         };
 
         Raw q[DEPTH];
-        vec_t pn_m, pn_c, pn_p, r_c;
-        T pne_c, pne_p, dummy;
+        vec_t pn_b, pn_c, pn_a, r_c;       // behind / centre / ahead rows in march order
+        T pne_c, pne_a, dummy;
         {
-            const Raw wm = fetch(ya - 1, false);
-            const Raw wc = fetch(ya, true);
+            const Raw wb = fetch(ystart - DIR, false);
+            const Raw wc = fetch(ystart, true);
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
-                if (ya + 1 + k <= yb + 1) q[k] = fetch(ya + 1 + k, true);
+                if (k + 1 <= nrows) q[k] = fetch(ystart + DIR * (k + 1), true);
                 else { Raw zz; for (int j = 0; j < VEC; ++j) { zz.r[j] = (T)0; zz.p[j] = (T)0; } zz.re = zz.pe = (T)0; q[k] = zz; }
             }
-            conv(wm, pn_m, dummy);
+            conv(wb, pn_b, dummy);
             conv(wc, pn_c, pne_c);
             r_c = wc.r;
         }
 
-        for (int yy = ya; yy <= yb; yy += DEPTH) {
+        for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
-                const int y = yy + k;
-                if (y <= yb) {
+                const int i = i0 + k;
+                if (i < nrows) {
+                    const int y = ystart + DIR * i;
                     const Raw w = q[k];
-                    if (y + 1 + DEPTH <= yb + 1) q[k] = fetch(y + 1 + DEPTH, true);
-                    conv(w, pn_p, pne_p);
+                    if (i + 1 + DEPTH <= nrows) q[k] = fetch(ystart + DIR * (i + 1 + DEPTH), true);
+                    conv(w, pn_a, pne_a);
 
                     // in-row neighbours: from the adjacent lane, wave-edge lanes use their edge load
                     T left0 = __shfl_up(pn_c[VEC - 1], 1, kWave);
@@ -279,6 +297,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
 
                     const int cmin = y <= g.half ? g.cb : 0;
                     const int xint0 = y <= g.half ? g.half + 1 : 1;     // first interior column of row y
+                    const vec_t& top = DESC ? pn_b : pn_a;              // row y+1
+                    const vec_t& bot = DESC ? pn_a : pn_b;              // row y-1
                     vec_t out;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
@@ -289,8 +309,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                         T v = cA * c;
                         v = v + cxk * L;
                         v = v + cxk * R;
-                        v = v + cyk * pn_p[j];
-                        v = v + cyk * pn_m[j];
+                        v = v + cyk * top[j];
+                        v = v + cyk * bot[j];
                         const int xj = x + j;
                         out[j] = (xj >= xint0 && xj <= g.N - 1) ? v : (T)0;
                         acc_pap += (double)c * (double)out[j];
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                         *reinterpret_cast<vec_t*>(a.ap + off) = out;
                         if (FUSED) *reinterpret_cast<vec_t*>(a.pout + off) = pn_c;
                     }
-                    pn_m = pn_c; pn_c = pn_p; pne_c = pne_p; r_c = w.r;
+                    pn_b = pn_c; pn_c = pn_a; pne_c = pne_a; r_c = w.r;
                 }
             }
         }
@@ -326,6 +346,7 @@ struct UpdateArgs {
     const CgState* s_in; CgState* s_out;
     int rule;                  // MSG: alpha = rz / Azz ; REL2: alpha = rr / pAp
     int init;                  // 1: alpha := 0, state initialisation (x = 0, r = b)
+    int reverse;               // flat kernel: sweep the range from its end to its start
 };
 
 template <typename T, int VEC, bool HAS_U>
@@ -357,7 +378,9 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     const vec_t* Q = reinterpret_cast<const vec_t*>(a.ap);
     const vec_t* Uu = reinterpret_cast<const vec_t*>(a.u);
 
-    auto body = [&](long long i) {
+    const long long last = a.begin + a.nvec - 1;
+    auto body = [&](long long i_fwd) {
+        const long long i = a.reverse ? last - (i_fwd - a.begin) : i_fwd;
         const vec_t x0 = X[i], pv = Pp[i], r0 = R[i], qv = Q[i];
         vec_t uv; if (HAS_U) uv = Uu[i];
         vec_t xn, rn;
@@ -383,6 +406,111 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     const long long end = a.begin + a.nvec;
     for (; i + stride < end; i += 2 * stride) { body(i); body(i + stride); }
     if (i < end) body(i);
+
+    const double t_rr = block_reduce<false>(s_rr, lds);
+    const double t_rmax = block_reduce<true>(s_rmax, lds);
+    const double t_dmax = block_reduce<true>(s_dmax, lds);
+    const double t_d2 = block_reduce<false>(s_d2, lds);
+    double t_emax = 0, t_e2 = 0;
+    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce<false>(s_e2, lds); }
+    if (threadIdx.x == 0) {
+        const int b = blockIdx.x, st = a.strideB;
+        a.partB[FB_RR * st + b] = t_rr;     a.partB[FB_RMAX * st + b] = t_rmax;
+        a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
+        a.partB[FB_D2 * st + b] = t_d2;     a.partB[FB_E2 * st + b] = t_e2;
+        if (blockIdx.x == 0) {
+            CgState o = s;
+            if (!a.init) { o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz; }
+            *a.s_out = o;
+        }
+    }
+}
+
+// 2-D variant of the update: same (chunk, strip) work items as the stencil, marched in the
+// opposite direction (see k_stencil).  Element-wise arithmetic identical to k_update.
+template <typename T>
+struct Update2DArgs {
+    Geom g;
+    WorkList wl;
+    UpdateArgs<T> u;
+};
+
+template <typename T, int VEC, bool HAS_U, int UNROLL, bool DESC>
+__global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
+    typedef typename VecOf<T, VEC>::type vec_t;
+    __shared__ double lds[kWaves];
+    const UpdateArgs<T>& a = aa.u;
+    const Geom& g = aa.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    CgState s;
+    double alpha_d = 0.0, rz = 0.0;
+    if (a.init) {
+        s = CgState{}; s.first = 1; s.it = 0;
+    } else {
+        s = *a.s_in;
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, lds);
+        if (a.rule == 0) {
+            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, lds);
+            alpha_d = rz / pap;                       // msg_solver.cpp:102
+        } else {
+            alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
+        }
+    }
+    const T alpha = (T)alpha_d;
+    double s_rr = 0, s_rmax = 0, s_dmax = 0, s_emax = 0, s_d2 = 0, s_e2 = 0;
+    constexpr int DIR = DESC ? -1 : 1;
+
+    for (int item = blockIdx.x * kWaves + wave; item < aa.wl.nitems; item += gridDim.x * kWaves) {
+        const Item it = decode_item(aa.wl, item);
+        const int x = it.strip * (kWave * VEC) + lane * VEC;
+        const bool xin = x < g.xlim;
+        const int nrows = it.yb - it.ya + 1;
+        const int ystart = DESC ? it.yb : it.ya;
+        for (int i0 = 0; i0 < nrows; i0 += UNROLL) {
+            vec_t x0[UNROLL], pv[UNROLL], r0[UNROLL], qv[UNROLL], uv[UNROLL];
+            long long off[UNROLL];
+            bool ok[UNROLL];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                const int y = ystart + DIR * (i0 + k);
+                ok[k] = (i0 + k < nrows) && xin && x >= (y <= g.half ? g.cb : 0);
+                off[k] = row_off(g, y) - g.base0 + x;
+                if (ok[k]) {
+                    x0[k] = *reinterpret_cast<const vec_t*>(a.x + off[k]);
+                    pv[k] = *reinterpret_cast<const vec_t*>(a.p + off[k]);
+                    r0[k] = *reinterpret_cast<const vec_t*>(a.r + off[k]);
+                    qv[k] = *reinterpret_cast<const vec_t*>(a.ap + off[k]);
+                    if (HAS_U) uv[k] = *reinterpret_cast<const vec_t*>(a.u + off[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                if (ok[k]) {
+                    vec_t xn, rn;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        xn[j] = x0[k][j] + alpha * pv[k][j];        // x = x + alpha*z     msg_solver.cpp:105-107
+                        rn[j] = r0[k][j] - alpha * qv[k][j];        // r = r - alpha*A_z   msg_solver.cpp:110-112
+                        const double rd = (double)rn[j];
+                        s_rr += rd * rd;
+                        s_rmax = fmax(s_rmax, fabs(rd));
+                        const double dd = (double)(xn[j] - x0[k][j]);   // diff = x - x_prev   :124-127
+                        s_dmax = fmax(s_dmax, fabs(dd));
+                        s_d2 += dd * dd;
+                        if (HAS_U) {
+                            const double ee = (double)(xn[j] - uv[k][j]);   // error = x - u    :132-136
+                            s_emax = fmax(s_emax, fabs(ee));
+                            s_e2 += ee * ee;
+                        }
+                    }
+                    *reinterpret_cast<vec_t*>(a.x + off[k]) = xn;
+                    *reinterpret_cast<vec_t*>(a.r + off[k]) = rn;
+                }
+            }
+        }
+    }
 
     const double t_rr = block_reduce<false>(s_rr, lds);
     const double t_rmax = block_reduce<true>(s_rmax, lds);

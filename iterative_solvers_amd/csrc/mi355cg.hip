@@ -64,6 +64,7 @@ struct mi355cg_ctx {
     long long pk_begin = 0, pk_len = 0; // owned packed range
     WorkList wl{};
     int grid_stencil = 0, grid_update = 0, rows_per_item = 0, depth = 4;
+    int update_mode = 1, stencil_desc = 1, update_desc = 0, update_unroll = 4;   // launch-shape knobs (env)
     int strideA = 0, strideB = 0;
 
     // device vectors in storage layout (fp64 set always; fp32 set for F32_MIXED)
@@ -150,7 +151,12 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     c->grid_stencil = std::max(1, std::min(max_blocks, (wl.nitems + kWaves - 1) / kWaves));
     const long long nvec = g.own_len / vec;
     const int max_upd = std::max(1, env_int("MI355CG_UPDATE_BLOCKS", 1024));
-    c->grid_update = (int)std::max<long long>(1, std::min<long long>(max_upd, (nvec + kBlock - 1) / kBlock));
+    c->update_mode = env_int("MI355CG_UPDATE_MODE", 1);          // 1: 2-D chunks shared with the stencil, 0: flat
+    c->stencil_desc = env_int("MI355CG_STENCIL_DESC", 1);        // stencil marches its chunks downwards ...
+    c->update_desc = env_int("MI355CG_UPDATE_DESC", 0);          // ... the update marches them upwards
+    c->update_unroll = env_int("MI355CG_UPDATE_UNROLL", 4);
+    if (c->update_mode == 1) c->grid_update = std::max(1, std::min(max_upd, (wl.nitems + kWaves - 1) / kWaves));
+    else c->grid_update = (int)std::max<long long>(1, std::min<long long>(max_upd, (nvec + kBlock - 1) / kBlock));
     c->depth = env_int("MI355CG_DEPTH", 4);
 }
 
@@ -161,14 +167,19 @@ PackGeom pack_geom(const mi355cg_ctx* c) {
 int flat_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>(2048, (n + kBlock - 1) / kBlock)); }
 
 // ---- launchers -------------------------------------------------------------------------------------
-template <typename T, int VEC, bool FUSED, bool MSG>
-void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a) {
+template <typename T, int VEC, bool FUSED, bool MSG, bool DESC>
+void launch_stencil_dir(const mi355cg_ctx* c, const StencilArgs<T>& a) {
     dim3 grid(c->grid_stencil), block(kBlock);
     switch (c->depth) {
-        case 2: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 2>), grid, block, 0, c->stream, a); break;
-        case 8: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 8>), grid, block, 0, c->stream, a); break;
-        default: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 4>), grid, block, 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 2, DESC>), grid, block, 0, c->stream, a); break;
+        case 8: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 8, DESC>), grid, block, 0, c->stream, a); break;
+        default: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 4, DESC>), grid, block, 0, c->stream, a); break;
     }
+}
+template <typename T, int VEC, bool FUSED, bool MSG>
+void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a) {
+    if (c->stencil_desc) launch_stencil_dir<T, VEC, FUSED, MSG, true>(c, a);
+    else launch_stencil_dir<T, VEC, FUSED, MSG, false>(c, a);
 }
 
 template <typename T, int VEC>
@@ -208,8 +219,23 @@ void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, c
     a.x = x; a.r = r; a.p = p; a.ap = ap; a.u = u;
     a.partA = c->partA; a.nA = c->grid_stencil; a.strideA = c->strideA;
     a.partB = c->partB; a.strideB = c->strideB;
-    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0;
+    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = c->update_desc;
     dim3 grid(c->grid_update), block(kBlock);
+    if (c->update_mode == 1) {
+        Update2DArgs<T> aa{};
+        aa.g = c->g; aa.g.xlim = (int)round_up(c->g.N + 1, VEC); aa.wl = c->wl; aa.u = a;
+#define MI355CG_U2D(HASU, UNR, DESC) hipLaunchKernelGGL((k_update2d<T, VEC, HASU, UNR, DESC>), grid, block, 0, c->stream, aa)
+        const bool d = c->update_desc != 0;
+        if (c->update_unroll == 2) {
+            if (cfg.has_u) { if (d) MI355CG_U2D(true, 2, true); else MI355CG_U2D(true, 2, false); }
+            else           { if (d) MI355CG_U2D(false, 2, true); else MI355CG_U2D(false, 2, false); }
+        } else {
+            if (cfg.has_u) { if (d) MI355CG_U2D(true, 4, true); else MI355CG_U2D(true, 4, false); }
+            else           { if (d) MI355CG_U2D(false, 4, true); else MI355CG_U2D(false, 4, false); }
+        }
+#undef MI355CG_U2D
+        return;
+    }
     if (cfg.has_u) hipLaunchKernelGGL((k_update<T, VEC, true>), grid, block, 0, c->stream, a);
     else hipLaunchKernelGGL((k_update<T, VEC, false>), grid, block, 0, c->stream, a);
 }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""In-process sweep of the launch-geometry knobs (env vars read at mi355cg_create).
+Usage: python tools/tune.py [N] [iters]"""
+import itertools
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import iterative_solvers_amd as isa
+from iterative_solvers_amd import _capi
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+U = (N // 2 - 1) * (3 * N // 2 - 1)
+
+
+def run(env):
+    for k, v in env.items():
+        os.environ[k] = str(v)
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    h = s._handle
+    p = isa.default_params(_capi.RULE_REL_2NORM)
+    p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = ITERS, 1, 0, 0, 500
+    h.solve(p)
+    t0 = time.perf_counter(); h.solve(p); dt = time.perf_counter() - t0
+    h.set_profiling(True); h.solve(p); h.set_profiling(False)
+    ts, tu = h.kernel_time(0)[0], h.kernel_time(1)[0]
+    lay = h.layout()
+    print(f"{env} its/s={ITERS/dt:8.1f} GB/s(88B)={88*U*ITERS/dt/1e9:7.1f} stencil={ts*1e3:7.1f}us ({32*U/ts/1e6:6.0f} GB/s) "
+          f"update={tu*1e3:7.1f}us ({48*U/tu/1e6:6.0f} GB/s) grid={lay['grid_stencil']}/{lay['grid_update']} ty={lay['rows_per_item']}", flush=True)
+    h.close()
+
+
+if __name__ == "__main__":
+    base = {"MI355CG_STENCIL_WAVES": 4096, "MI355CG_STENCIL_BLOCKS": 1024, "MI355CG_DEPTH": 4, "MI355CG_UPDATE_BLOCKS": 1024,
+            "MI355CG_UPDATE_MODE": 0, "MI355CG_STENCIL_DESC": 0, "MI355CG_UPDATE_DESC": 0, "MI355CG_UPDATE_UNROLL": 4, "MI355CG_ROWS": 0}
+    run(base)
+    run({**base, "MI355CG_UPDATE_DESC": 1})
+    for rows in (6, 8, 12, 16):
+        for blocks in (512, 1024, 2048):
+            run({**base, "MI355CG_ROWS": rows, "MI355CG_STENCIL_BLOCKS": blocks, "MI355CG_UPDATE_DESC": 1})
+        run({**base, "MI355CG_ROWS": rows, "MI355CG_UPDATE_DESC": 0})
+    run({**base, "MI355CG_ROWS": 8, "MI355CG_UPDATE_DESC": 1, "MI355CG_DEPTH": 2})
+    run({**base, "MI355CG_ROWS": 8, "MI355CG_UPDATE_DESC": 1, "MI355CG_UPDATE_BLOCKS": 512})
+    run({**base, "MI355CG_ROWS": 8, "MI355CG_UPDATE_DESC": 1, "MI355CG_UPDATE_BLOCKS": 2048})
