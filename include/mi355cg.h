@@ -129,6 +129,34 @@ int  mi355cg_get_kernel_time(mi355cg_handle h, int kernel, double *avg_ms, long 
 int  mi355cg_get_layout(mi355cg_handle h, long long *padded_len, int *pitch_bottom, int *pitch_upper,
                         int *grid_stencil, int *grid_update, int *rows_per_item);
 
+/* ---- multi-GPU: one context per rank, one contiguous slab of grid rows per context --------------
+ * The reference is single-process (no collectives exist in it); this is the scaling
+ * surface.  The grid is cut into row slabs balanced by unknown count.  The library runs the
+ * kernels; the caller (iterative_solvers_amd/distributed.py over torch.distributed = RCCL)
+ * moves the two things that cross ranks each phase: ghost rows (mi355cg_dist_halo) and the
+ * per-rank reduced partials (mi355cg_dist_sums_ptr -> all_gather -> gathered_* arguments).
+ * Every rank reduces the gathered partials in rank order, so all ranks take identical decisions.
+ * All dist calls are asynchronous on `stream` (NULL = the context's own stream).
+ * Host vectors of a slab context (get_rhs, get_solution, ...) cover only its owned packed range. */
+int  mi355cg_slab_rows(int n, int world, int rank, int *y_lo, int *y_hi);
+int  mi355cg_create_slab(int n, int m, double a, double b, double c, double d, int dtype, int device,
+                         int y_lo, int y_hi, mi355cg_handle *out);
+int  mi355cg_owned_range(mi355cg_handle h, long long *packed_begin, long long *packed_len, int *y_lo, int *y_hi);
+int  mi355cg_dist_begin(mi355cg_handle h, const mi355cg_params *params, void *stream);
+int  mi355cg_dist_reduce(mi355cg_handle h, int which /*0 stencil, 1 update*/, void *stream);
+int  mi355cg_dist_sums_ptr(mi355cg_handle h, int which, void **dev_ptr, int *count);
+int  mi355cg_dist_stencil(mi355cg_handle h, const double *gathered_update_sums, int nranks,
+                          int rows /*0 all, 1 interior, 2 edge rows*/, void *stream);
+int  mi355cg_dist_flip(mi355cg_handle h);          /* once per stencil phase: new direction becomes current */
+int  mi355cg_dist_update(mi355cg_handle h, const double *gathered_stencil_sums, int nranks, void *stream);
+int  mi355cg_dist_check(mi355cg_handle h, const double *gathered_update_sums, int nranks, void *stream);
+int  mi355cg_dist_summary(mi355cg_handle h, mi355cg_results *out, int *done);   /* after a stream sync */
+int  mi355cg_dist_history(mi355cg_handle h, int iteration, double *precision, double *residual, double *error);
+int  mi355cg_dist_halo(mi355cg_handle h, int vector /*0 r, 1 current direction*/,
+                       void **send_lo, void **recv_lo, long long *n_send_lo,
+                       void **send_hi, void **recv_hi, long long *n_send_hi);
+int  mi355cg_dist_halo_recv_counts(mi355cg_handle h, long long *n_from_lo, long long *n_from_hi);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,10 @@ EXPORTS = [
     "mi355cg_apply", "mi355cg_apply_device", "mi355cg_default_params", "mi355cg_solve",
     "mi355cg_get_solution", "mi355cg_get_recursive_residual", "mi355cg_get_true_residual",
     "mi355cg_set_profiling", "mi355cg_get_kernel_time", "mi355cg_get_layout",
+    "mi355cg_slab_rows", "mi355cg_create_slab", "mi355cg_owned_range", "mi355cg_dist_begin",
+    "mi355cg_dist_reduce", "mi355cg_dist_sums_ptr", "mi355cg_dist_stencil", "mi355cg_dist_flip",
+    "mi355cg_dist_update", "mi355cg_dist_check", "mi355cg_dist_summary", "mi355cg_dist_history",
+    "mi355cg_dist_halo", "mi355cg_dist_halo_recv_counts",
 ]
 
 
@@ -88,6 +92,22 @@ def load():
     L.mi355cg_set_profiling.argtypes = [H, C.c_int]
     L.mi355cg_get_kernel_time.argtypes = [H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.mi355cg_get_layout.argtypes = [H, C.POINTER(C.c_longlong)] + [C.POINTER(C.c_int)] * 5
+    LLP, IP, VPP = C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_void_p)
+    L.mi355cg_slab_rows.argtypes = [C.c_int, C.c_int, C.c_int, IP, IP]
+    L.mi355cg_create_slab.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int] * 4 + [C.POINTER(H)]
+    L.mi355cg_owned_range.argtypes = [H, LLP, LLP, IP, IP]
+    L.mi355cg_dist_begin.argtypes = [H, C.POINTER(Params), C.c_void_p]
+    L.mi355cg_dist_reduce.argtypes = [H, C.c_int, C.c_void_p]
+    L.mi355cg_dist_sums_ptr.argtypes = [H, C.c_int, VPP, IP]
+    L.mi355cg_dist_stencil.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mi355cg_dist_flip.argtypes = [H]
+    L.mi355cg_dist_update.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p]
+    L.mi355cg_dist_check.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p]
+    L.mi355cg_dist_summary.argtypes = [H, C.POINTER(Results), IP]
+    DBP = C.POINTER(C.c_double)
+    L.mi355cg_dist_history.argtypes = [H, C.c_int, DBP, DBP, DBP]
+    L.mi355cg_dist_halo.argtypes = [H, C.c_int, VPP, VPP, LLP, VPP, VPP, LLP]
+    L.mi355cg_dist_halo_recv_counts.argtypes = [H, LLP, LLP]
     _lib = L
     return L
 

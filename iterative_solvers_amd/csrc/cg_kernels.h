@@ -102,10 +102,12 @@ __device__ inline double block_reduce(double v, double* lds /* >= kWaves doubles
     return t;
 }
 // Reduce `n` partials of one field (thread t takes t, t+256, ... in ascending order).
+// `es` = element stride: 1 for a kernel's own field-major partials, the field count for partials
+// all-gathered rank-major across GPUs ([rank][field]).
 template <bool IS_MAX>
-__device__ inline double reduce_parts(const double* __restrict__ part, int n, double* lds) {
+__device__ inline double reduce_parts(const double* __restrict__ part, int n, int es, double* lds) {
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += kBlock) v = IS_MAX ? fmax(v, part[i]) : v + part[i];
+    for (int i = threadIdx.x; i < n; i += kBlock) v = IS_MAX ? fmax(v, part[(long long)i * es]) : v + part[(long long)i * es];
     return block_reduce<IS_MAX>(v, lds);
 }
 
@@ -151,17 +153,17 @@ __device__ inline void write_state_after_decision(CgState* out, HistEntry* hist,
 
 // Reduce the update kernel's partials (only the fields the rule needs) and decide.
 __device__ inline Decision reduce_and_decide(const CgState& s, const RuleParams& rp, const double* partB,
-                                             int nB, int strideB, int want_diag, double* lds) {
-    const double rr = reduce_parts<false>(partB + FB_RR * strideB, nB, lds);
+                                             int nB, int strideB, int esB, int want_diag, double* lds) {
+    const double rr = reduce_parts<false>(partB + FB_RR * strideB, nB, esB, lds);
     double rmax = 0, dmax = 0, emax = 0, d2 = 0, e2 = 0;
     if (rp.rule == 0 || want_diag) {
-        rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, lds);
-        dmax = reduce_parts<true>(partB + FB_DMAX * strideB, nB, lds);
-        if (rp.use_u) emax = reduce_parts<true>(partB + FB_EMAX * strideB, nB, lds);
+        rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, esB, lds);
+        dmax = reduce_parts<true>(partB + FB_DMAX * strideB, nB, esB, lds);
+        if (rp.use_u) emax = reduce_parts<true>(partB + FB_EMAX * strideB, nB, esB, lds);
     }
     if (want_diag) {
-        d2 = reduce_parts<false>(partB + FB_D2 * strideB, nB, lds);
-        if (rp.use_u) e2 = reduce_parts<false>(partB + FB_E2 * strideB, nB, lds);
+        d2 = reduce_parts<false>(partB + FB_D2 * strideB, nB, esB, lds);
+        if (rp.use_u) e2 = reduce_parts<false>(partB + FB_E2 * strideB, nB, esB, lds);
     }
     return decide_after_update(s, rp, rr, rmax, dmax, emax, d2, e2);
 }
@@ -175,8 +177,8 @@ struct StencilArgs {
     const T* pin;        // FUSED: previous direction; PLAIN: the vector to apply the operator to
     T* pout;             // FUSED: new direction (ping-pong partner of pin)
     T* ap;               // A_h * (new direction | input vector)
-    const double* partB; int nB, strideB;       // update-kernel partials to reduce in the prologue
-    double* partA; int strideA;                 // this kernel's partials (field-major)
+    const double* partB; int nB, strideB, esB;  // update-kernel partials to reduce in the prologue (count, field stride, element stride)
+    double* partA; int strideA, slotA;          // this kernel's partials (field-major); first slot of this launch
     const CgState* s_in; CgState* s_out;        // state written by the update kernel / by this kernel
     HistEntry* hist;
     RuleParams rp;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     if (FUSED) {
         const CgState s = *a.s_in;
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
-        const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.want_diag, lds);
+        const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, a.want_diag, lds);
         if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, s, d);
         if (d.done) return;
         beta = (T)d.beta;
@@ -331,8 +333,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     double tz = 0.0;
     if (MSG) tz = block_reduce<false>(acc_rz, lds);
     if (threadIdx.x == 0 && a.partA) {
-        a.partA[FA_PAP * a.strideA + blockIdx.x] = tp;
-        a.partA[FA_RZ * a.strideA + blockIdx.x] = tz;
+        a.partA[FA_PAP * a.strideA + a.slotA + blockIdx.x] = tp;
+        a.partA[FA_RZ * a.strideA + a.slotA + blockIdx.x] = tz;
     }
 }
 
@@ -341,7 +343,7 @@ template <typename T>
 struct UpdateArgs {
     long long begin, nvec;     // owned flat range in units of VEC elements (begin is a vec index)
     T* x; T* r; const T* p; const T* ap; const T* u;
-    const double* partA; int nA, strideA;
+    const double* partA; int nA, strideA, esA;
     double* partB; int strideB;
     const CgState* s_in; CgState* s_out;
     int rule;                  // MSG: alpha = rz / Azz ; REL2: alpha = rr / pAp
@@ -360,9 +362,9 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     } else {
         s = *a.s_in;
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
-        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, lds);
+        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, a.esA, lds);
         if (a.rule == 0) {
-            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, lds);
+            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, a.esA, lds);
             alpha_d = rz / pap;                       // msg_solver.cpp:102
         } else {
             alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
@@ -450,9 +452,9 @@ __global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
     } else {
         s = *a.s_in;
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
-        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, lds);
+        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, a.esA, lds);
         if (a.rule == 0) {
-            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, lds);
+            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, a.esA, lds);
             alpha_d = rz / pap;                       // msg_solver.cpp:102
         } else {
             alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
 
 // ---- end-of-chunk check: same decision as the next stencil prologue, without advancing -------------
 struct CheckArgs {
-    const double* partB; int nB, strideB;
+    const double* partB; int nB, strideB, esB;
     const CgState* s_in;      // state written by the last update kernel
     CgState* summary;         // device copy that the host reads
     HistEntry* hist;
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
     __shared__ double lds[kWaves];
     const CgState s = *a.s_in;
     if (s.done) { if (threadIdx.x == 0) *a.summary = s; return; }
-    const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, 1, lds);
+    const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, 1, lds);
     if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, s, d);
 }
 
@@ -553,8 +555,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts(const double* part, int
                                                         unsigned max_mask, double* out) {
     __shared__ double lds[kWaves];
     for (int f = 0; f < nf; ++f) {
-        const double v = ((max_mask >> f) & 1u) ? reduce_parts<true>(part + f * stride, n, lds)
-                                                : reduce_parts<false>(part + f * stride, n, lds);
+        const double v = ((max_mask >> f) & 1u) ? reduce_parts<true>(part + f * stride, n, 1, lds)
+                                                : reduce_parts<false>(part + f * stride, n, 1, lds);
         if (threadIdx.x == 0) out[f] = v;
     }
 }

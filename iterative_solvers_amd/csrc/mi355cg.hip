@@ -62,7 +62,8 @@ struct mi355cg_ctx {
     Geom g{};
     long long storage_len = 0;          // elements per vector incl. ghost rows
     long long pk_begin = 0, pk_len = 0; // owned packed range
-    WorkList wl{};
+    WorkList wl{}, wl_int{}, wl_edge{};   // whole slab; interior rows; first+last owned row
+    int grid_int = 0, grid_edge = 0;
     int grid_stencil = 0, grid_update = 0, rows_per_item = 0, depth = 4;
     int update_mode = 1, stencil_desc = 1, update_desc = 0, update_unroll = 4;   // launch-shape knobs (env)
     int strideA = 0, strideB = 0;
@@ -72,6 +73,9 @@ struct mi355cg_ctx {
     float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr, *bf = nullptr;
     double* packed = nullptr;           // device scratch, pk_len doubles
     double *partA = nullptr, *partB = nullptr, *partR = nullptr;
+    double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's reduced partials (feed the all-gather)
+    mi355cg_params dist_prm{};                    // slab mode: parameters given to mi355cg_dist_begin
+    bool dist_active = false, is_slab = false;
     CgState *sA = nullptr, *sB = nullptr, *summary = nullptr;
     HistEntry* hist = nullptr;
     CgState* summary_h = nullptr;       // pinned
@@ -81,6 +85,7 @@ struct mi355cg_ctx {
     std::vector<double> rhs_h, u_h;     // packed host copies (owned range)
     bool have_u_dev = false, solved = false;
     int cur = 0;                        // p[cur] holds the current direction after the last stencil
+    int nA_dist = 0;                    // slab mode: stencil partial slots written by the last stencil phase
 
     bool profiling = false;
     EventPool events;
@@ -114,31 +119,25 @@ void build_geom(mi355cg_ctx* c, int vec, int y_lo, int y_hi) {
     c->pk_len = (y_hi + 1 <= gp.n - 1 ? packed_row_begin(gp, y_hi + 1) : gp.size) - c->pk_begin;
 }
 
-// Cut the owned rows into (chunk, strip) items: one wave marches `ty` rows of a 64*vec-column strip.
-void build_worklist(mi355cg_ctx* c, int vec) {
-    const Geom& g = c->g;
+// Cut rows [ya, yb] into (chunk, strip) items: one wave marches `ty` rows of a 64*vec-column strip.
+// Appends up to two panels (bottom-right block rows, upper block rows); returns the strip-rows added.
+long long add_panels(const Geom& g, int vec, int ya, int yb, int ty, WorkList& wl) {
     const int sw = kWave * vec;
-    WorkList& wl = c->wl;
-    wl.np = 0; wl.nitems = 0;
+    const int ns_all = (g.N - 1) / sw + 1;
     struct Rect { int y0, y1, s0, ns; } rects[2];
     int nr = 0;
-    const int ns_all = (g.N - 1) / sw + 1;
-    if (g.y_lo <= g.half) {                                   // bottom-right block rows
+    if (ya <= g.half && yb >= 1) {                            // bottom-right block rows
         const int s0 = (g.half + 1) / sw;
-        rects[nr++] = {std::max(g.y_lo, 1), std::min(g.y_hi, g.half), s0, ns_all - s0};
+        rects[nr++] = {std::max(ya, 1), std::min(yb, g.half), s0, ns_all - s0};
     }
-    if (g.y_hi > g.half)                                      // upper block rows
-        rects[nr++] = {std::max(g.y_lo, g.half + 1), std::min(g.y_hi, g.N - 1), 0, ns_all};
+    if (yb > g.half)                                          // upper block rows
+        rects[nr++] = {std::max(ya, g.half + 1), std::min(yb, g.N - 1), 0, ns_all};
     long long strip_rows = 0;
-    for (int i = 0; i < nr; ++i) strip_rows += (long long)(rects[i].y1 - rects[i].y0 + 1) * rects[i].ns;
-    const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 2048));
-    int ty = (int)((strip_rows + target_waves - 1) / target_waves);
-    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), std::min(ty, 512));
-    if (env_int("MI355CG_ROWS", 0) > 0) ty = env_int("MI355CG_ROWS", 0);
-    c->rows_per_item = ty;
     for (int i = 0; i < nr; ++i) {
         const int rows = rects[i].y1 - rects[i].y0 + 1;
-        if (rows <= 0) continue;
+        if (rows <= 0 || wl.np >= kMaxPanels) continue;
+        strip_rows += (long long)rows * rects[i].ns;
+        if (ty <= 0) continue;                                // dry run: only count
         Panel& P = wl.p[wl.np++];
         P.y0 = rects[i].y0; P.y1 = rects[i].y1; P.s0 = rects[i].s0; P.ns = rects[i].ns;
         P.nchunks = (rows + ty - 1) / ty;
@@ -147,15 +146,36 @@ void build_worklist(mi355cg_ctx* c, int vec) {
         P.item0 = wl.nitems;
         wl.nitems += P.ns * P.nchunks;
     }
+    return strip_rows;
+}
+
+void build_worklist(mi355cg_ctx* c, int vec) {
+    const Geom& g = c->g;
+    WorkList dry{}; 
+    const long long strip_rows = add_panels(g, vec, g.y_lo, g.y_hi, 0, dry);
+    const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 4096));
+    int ty = (int)((strip_rows + target_waves - 1) / target_waves);
+    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), std::min(ty, 512));
+    if (env_int("MI355CG_ROWS", 0) > 0) ty = env_int("MI355CG_ROWS", 0);
+    c->rows_per_item = ty;
+    c->wl = WorkList{};
+    add_panels(g, vec, g.y_lo, g.y_hi, ty, c->wl);
     const int max_blocks = std::max(1, env_int("MI355CG_STENCIL_BLOCKS", 1024));
-    c->grid_stencil = std::max(1, std::min(max_blocks, (wl.nitems + kWaves - 1) / kWaves));
+    c->grid_stencil = std::max(1, std::min(max_blocks, (c->wl.nitems + kWaves - 1) / kWaves));
+    // slab split for halo/compute overlap: edge rows (need the neighbours' ghost rows) and interior rows
+    c->wl_edge = WorkList{}; c->wl_int = WorkList{};
+    add_panels(g, vec, g.y_lo, g.y_lo, 1, c->wl_edge);
+    if (g.y_hi > g.y_lo) add_panels(g, vec, g.y_hi, g.y_hi, 1, c->wl_edge);
+    if (g.y_hi - g.y_lo >= 2) add_panels(g, vec, g.y_lo + 1, g.y_hi - 1, ty, c->wl_int);
+    c->grid_edge = std::max(1, (c->wl_edge.nitems + kWaves - 1) / kWaves);
+    c->grid_int = std::max(1, std::min(max_blocks, (c->wl_int.nitems + kWaves - 1) / kWaves));
     const long long nvec = g.own_len / vec;
-    const int max_upd = std::max(1, env_int("MI355CG_UPDATE_BLOCKS", 1024));
-    c->update_mode = env_int("MI355CG_UPDATE_MODE", 1);          // 1: 2-D chunks shared with the stencil, 0: flat
-    c->stencil_desc = env_int("MI355CG_STENCIL_DESC", 1);        // stencil marches its chunks downwards ...
-    c->update_desc = env_int("MI355CG_UPDATE_DESC", 0);          // ... the update marches them upwards
+    const int max_upd = std::max(1, env_int("MI355CG_UPDATE_BLOCKS", 512));
+    c->update_mode = env_int("MI355CG_UPDATE_MODE", 0);          // 0: flat sweep, 1: 2-D chunks shared with the stencil
+    c->stencil_desc = env_int("MI355CG_STENCIL_DESC", 0);        // march direction of the stencil chunks
+    c->update_desc = env_int("MI355CG_UPDATE_DESC", 0);          // sweep direction of the update
     c->update_unroll = env_int("MI355CG_UPDATE_UNROLL", 4);
-    if (c->update_mode == 1) c->grid_update = std::max(1, std::min(max_upd, (wl.nitems + kWaves - 1) / kWaves));
+    if (c->update_mode == 1) c->grid_update = std::max(1, std::min(max_upd, (c->wl.nitems + kWaves - 1) / kWaves));
     else c->grid_update = (int)std::max<long long>(1, std::min<long long>(max_upd, (nvec + kBlock - 1) / kBlock));
     c->depth = env_int("MI355CG_DEPTH", 4);
 }
@@ -167,64 +187,76 @@ PackGeom pack_geom(const mi355cg_ctx* c) {
 int flat_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>(2048, (n + kBlock - 1) / kBlock)); }
 
 // ---- launchers -------------------------------------------------------------------------------------
+// Where a consumer kernel finds the partials it reduces in its prologue: the producer kernel's own
+// field-major array (estride 1) or partials all-gathered across ranks, rank-major (estride = #fields).
+struct PartSrc { const double* ptr; int n, fstride, estride; };
+// Which rows a stencil launch covers and where it runs.
+struct StencilWhere { hipStream_t stream; const WorkList* wl; int grid; int slotA; };
+
 template <typename T, int VEC, bool FUSED, bool MSG, bool DESC>
-void launch_stencil_dir(const mi355cg_ctx* c, const StencilArgs<T>& a) {
-    dim3 grid(c->grid_stencil), block(kBlock);
+void launch_stencil_dir(const mi355cg_ctx* c, const StencilArgs<T>& a, const StencilWhere& w) {
+    dim3 grid(w.grid), block(kBlock);
     switch (c->depth) {
-        case 2: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 2, DESC>), grid, block, 0, c->stream, a); break;
-        case 8: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 8, DESC>), grid, block, 0, c->stream, a); break;
-        default: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 4, DESC>), grid, block, 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 2, DESC>), grid, block, 0, w.stream, a); break;
+        case 8: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 8, DESC>), grid, block, 0, w.stream, a); break;
+        default: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 4, DESC>), grid, block, 0, w.stream, a); break;
     }
 }
 template <typename T, int VEC, bool FUSED, bool MSG>
-void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a) {
-    if (c->stencil_desc) launch_stencil_dir<T, VEC, FUSED, MSG, true>(c, a);
-    else launch_stencil_dir<T, VEC, FUSED, MSG, false>(c, a);
+void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a, const StencilWhere& w) {
+    if (c->stencil_desc) launch_stencil_dir<T, VEC, FUSED, MSG, true>(c, a, w);
+    else launch_stencil_dir<T, VEC, FUSED, MSG, false>(c, a, w);
 }
 
 template <typename T, int VEC>
-StencilArgs<T> stencil_args_common(const mi355cg_ctx* c) {
+StencilArgs<T> stencil_args_common(const mi355cg_ctx* c, const StencilWhere& w) {
     StencilArgs<T> a{};
     a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC);
-    a.wl = c->wl;
+    a.wl = *w.wl;
     return a;
 }
+StencilWhere whole_slab(const mi355cg_ctx* c) { return StencilWhere{c->stream, &c->wl, c->grid_stencil, 0}; }
 
 // y = A_h v (plain operator apply on storage-layout vectors)
 template <typename T, int VEC>
 void launch_apply(const mi355cg_ctx* c, const T* v, T* out) {
-    StencilArgs<T> a = stencil_args_common<T, VEC>(c);
+    const StencilWhere w = whole_slab(c);
+    StencilArgs<T> a = stencil_args_common<T, VEC>(c, w);
     a.pin = v; a.ap = out; a.partA = nullptr;
-    launch_stencil_depth<T, VEC, false, false>(c, a);
+    launch_stencil_depth<T, VEC, false, false>(c, a, w);
 }
 
 struct IterCfg { RuleParams rp; int want_diag; bool has_u; };
 
+// Phase A'.  Does NOT flip c->cur (a slab's interior and edge launches share one direction pair).
 template <typename T, int VEC>
-void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], T* ap) {
-    StencilArgs<T> a = stencil_args_common<T, VEC>(c);
+void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], T* ap,
+                              const StencilWhere& w, const PartSrc& pb) {
+    StencilArgs<T> a = stencil_args_common<T, VEC>(c, w);
     a.r = r; a.pin = p[c->cur]; a.pout = p[c->cur ^ 1]; a.ap = ap;
-    a.partB = c->partB; a.nB = c->grid_update; a.strideB = c->strideB;
-    a.partA = c->partA; a.strideA = c->strideA;
+    a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
+    a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slotA;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
-    if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a);
-    else launch_stencil_depth<T, VEC, true, false>(c, a);
-    c->cur ^= 1;
+    if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a, w);
+    else launch_stencil_depth<T, VEC, true, false>(c, a, w);
 }
+PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, c->grid_update, c->strideB, 1}; }
+PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, c->grid_stencil, c->strideA, 1}; }
 
 template <typename T, int VEC>
-void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, bool init) {
+void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, bool init,
+                   hipStream_t stream, const PartSrc& pa) {
     UpdateArgs<T> a{};
     a.begin = c->g.own_begin / VEC; a.nvec = c->g.own_len / VEC;
     a.x = x; a.r = r; a.p = p; a.ap = ap; a.u = u;
-    a.partA = c->partA; a.nA = c->grid_stencil; a.strideA = c->strideA;
+    a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
     a.partB = c->partB; a.strideB = c->strideB;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = c->update_desc;
     dim3 grid(c->grid_update), block(kBlock);
     if (c->update_mode == 1) {
         Update2DArgs<T> aa{};
         aa.g = c->g; aa.g.xlim = (int)round_up(c->g.N + 1, VEC); aa.wl = c->wl; aa.u = a;
-#define MI355CG_U2D(HASU, UNR, DESC) hipLaunchKernelGGL((k_update2d<T, VEC, HASU, UNR, DESC>), grid, block, 0, c->stream, aa)
+#define MI355CG_U2D(HASU, UNR, DESC) hipLaunchKernelGGL((k_update2d<T, VEC, HASU, UNR, DESC>), grid, block, 0, stream, aa)
         const bool d = c->update_desc != 0;
         if (c->update_unroll == 2) {
             if (cfg.has_u) { if (d) MI355CG_U2D(true, 2, true); else MI355CG_U2D(true, 2, false); }
@@ -236,15 +268,29 @@ void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, c
 #undef MI355CG_U2D
         return;
     }
-    if (cfg.has_u) hipLaunchKernelGGL((k_update<T, VEC, true>), grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_update<T, VEC, false>), grid, block, 0, c->stream, a);
+    if (cfg.has_u) hipLaunchKernelGGL((k_update<T, VEC, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_update<T, VEC, false>), grid, block, 0, stream, a);
 }
 
-void launch_check(mi355cg_ctx* c, const IterCfg& cfg) {
+void launch_check(mi355cg_ctx* c, const IterCfg& cfg, hipStream_t stream, const PartSrc& pb) {
     CheckArgs a{};
-    a.partB = c->partB; a.nB = c->grid_update; a.strideB = c->strideB;
+    a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
     a.s_in = c->sB; a.summary = c->summary; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
-    hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, c->stream, a);
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, stream, a);
+}
+
+IterCfg make_cfg(const mi355cg_params* prm) {
+    IterCfg cfg{};
+    const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
+    cfg.rp.rule = prm->rule; cfg.rp.max_iterations = prm->max_iterations;
+    cfg.rp.eps_precision = prm->eps_precision; cfg.rp.eps_residual = prm->eps_residual;
+    cfg.rp.eps_exact_error = prm->eps_exact_error; cfg.rp.eps_rel = prm->eps_rel;
+    cfg.rp.fixed_iterations = prm->fixed_iterations;
+    const bool diag = !msg && prm->diagnostics;
+    cfg.has_u = (msg && prm->use_true_solution) || diag;
+    cfg.rp.use_u = cfg.has_u ? 1 : 0;
+    cfg.want_diag = diag ? 1 : 0;
+    return cfg;
 }
 
 template <typename T>
@@ -312,7 +358,8 @@ extern "C" {
 const char* mi355cg_last_error(void) { return g_err.c_str(); }
 const char* mi355cg_version(void) { return "mi355cg 0.1 (gfx950)"; }
 
-int mi355cg_create(int n, int m, double a, double b, double c_, double d, int dtype, int device, mi355cg_handle* out) {
+static int create_impl(int n, int m, double a, double b, double c_, double d, int dtype, int device,
+                       int y_lo, int y_hi, bool slab, mi355cg_handle* out) {
     if (!out) return fail(MI355CG_ERR_INVALID, "out is null");
     *out = nullptr;
     if (dtype != MI355CG_F64 && dtype != MI355CG_F32_MIXED) return fail(MI355CG_ERR_INVALID, "unknown dtype %d", dtype);
@@ -325,12 +372,15 @@ int mi355cg_create(int n, int m, double a, double b, double c_, double d, int dt
     if (device < 0 || device >= ndev) return fail(MI355CG_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
     HIPCK(hipSetDevice(device));
 
+    if (!slab) { y_lo = 1; y_hi = gp.n - 1; }
+    if (y_lo < 1 || y_hi > gp.n - 1 || y_lo > y_hi)
+        return fail(MI355CG_ERR_INVALID, "slab rows [%d, %d] outside 1..%d", y_lo, y_hi, gp.n - 1);
     mi355cg_ctx* c = new mi355cg_ctx();
-    c->device = device; c->dtype = dtype; c->gp = gp;
+    c->device = device; c->dtype = dtype; c->gp = gp; c->is_slab = slab;
     const int vec = 2;                      // fp64 layout; the fp32 kernels use VEC=4 on the same pitches
-    build_geom(c, vec, 1, gp.n - 1);
+    build_geom(c, vec, y_lo, y_hi);
     build_worklist(c, vec);
-    c->strideA = c->grid_stencil; c->strideB = c->grid_update;
+    c->strideA = std::max(c->grid_stencil, c->grid_int + c->grid_edge); c->strideB = c->grid_update;
 
     int rc = MI355CG_OK;
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
@@ -342,6 +392,8 @@ int mi355cg_create(int n, int m, double a, double b, double c_, double d, int dt
     if ((rc = alloc_vec(&c->partA, (long long)FA_COUNT * c->strideA))) return cleanup();
     if ((rc = alloc_vec(&c->partB, (long long)FB_COUNT * c->strideB))) return cleanup();
     if ((rc = alloc_vec(&c->partR, 2048))) return cleanup();
+    if ((rc = alloc_vec(&c->sumsA, FA_COUNT))) return cleanup();
+    if ((rc = alloc_vec(&c->sumsB, FB_COUNT))) return cleanup();
     if (hipMalloc((void**)&c->sA, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->sB, sizeof(CgState)) != hipSuccess ||
         hipMalloc((void**)&c->summary, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->hist, sizeof(HistEntry) * kHist) != hipSuccess ||
         hipHostMalloc((void**)&c->summary_h, sizeof(CgState)) != hipSuccess || hipHostMalloc((void**)&c->hist_h, sizeof(HistEntry) * kHist) != hipSuccess ||
@@ -359,12 +411,20 @@ int mi355cg_create(int n, int m, double a, double b, double c_, double d, int dt
     return MI355CG_OK;
 }
 
+int mi355cg_create(int n, int m, double a, double b, double c_, double d, int dtype, int device, mi355cg_handle* out) {
+    return create_impl(n, m, a, b, c_, d, dtype, device, 0, 0, false, out);
+}
+int mi355cg_create_slab(int n, int m, double a, double b, double c_, double d, int dtype, int device,
+                        int y_lo, int y_hi, mi355cg_handle* out) {
+    return create_impl(n, m, a, b, c_, d, dtype, device, y_lo, y_hi, true, out);
+}
+
 void mi355cg_destroy(mi355cg_handle c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->xf, c->rf, c->pf[0], c->pf[1], c->apf, c->bf,
-                   c->packed, c->partA, c->partB, c->partR, c->sA, c->sB, c->summary, c->hist};
+                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
     for (void* p : dev) if (p) hipFree(p);
     if (c->summary_h) hipHostFree(c->summary_h);
     if (c->hist_h) hipHostFree(c->hist_h);
@@ -440,15 +500,8 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     if (c->dtype != MI355CG_F64) return fail(MI355CG_ERR_INVALID, "F32_MIXED solve is not wired in this build yet");
     HIPCK(hipSetDevice(c->device));
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
-    IterCfg cfg{};
-    cfg.rp.rule = prm->rule; cfg.rp.max_iterations = prm->max_iterations;
-    cfg.rp.eps_precision = prm->eps_precision; cfg.rp.eps_residual = prm->eps_residual;
-    cfg.rp.eps_exact_error = prm->eps_exact_error; cfg.rp.eps_rel = prm->eps_rel;
-    cfg.rp.fixed_iterations = prm->fixed_iterations;
-    const bool diag = !msg && prm->diagnostics;
-    cfg.has_u = (msg && prm->use_true_solution) || diag;
-    cfg.rp.use_u = cfg.has_u ? 1 : 0;
-    cfg.want_diag = diag ? 1 : 0;
+    const IterCfg cfg = make_cfg(prm);
+    const bool diag = cfg.want_diag != 0;
     if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -462,11 +515,11 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     HIPCK(hipMemsetAsync(c->ap, 0, bytes, c->stream));
     HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
     c->cur = 0;
-    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, /*init=*/true);
+    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, /*init=*/true, c->stream, own_partA(c));
     HIPCK(hipGetLastError());
 
     auto poll = [&]() -> int {
-        launch_check(c, cfg);
+        launch_check(c, cfg, c->stream, own_partB(c));
         HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipMemcpyAsync(c->hist_h, c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipStreamSynchronize(c->stream));
@@ -489,10 +542,11 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         for (int k = 0; k < m; ++k) {
             hipEvent_t e0 = nullptr;
             prof_begin(c, 0, &e0);
-            launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap);
+            launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, whole_slab(c), own_partB(c));
+            c->cur ^= 1;
             prof_end(c, 0, e0);
             prof_begin(c, 1, &e0);
-            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false);
+            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c));
             prof_end(c, 1, e0);
             if (diag) {
                 // MatrixFreeSolver's per-iteration report: second apply for the TRUE residual
@@ -588,6 +642,169 @@ int mi355cg_get_layout(mi355cg_handle c, long long* padded_len, int* pitch_botto
     if (grid_stencil) *grid_stencil = c->grid_stencil;
     if (grid_update) *grid_update = c->grid_update;
     if (rows_per_item) *rows_per_item = c->rows_per_item;
+    return MI355CG_OK;
+}
+
+
+// ---- slab (one rank of a row-decomposed grid) ------------------------------------------------------
+int mi355cg_slab_rows(int n, int world, int rank, int* y_lo, int* y_hi) {
+    GridParams gp;
+    if (!grid_params_init(&gp, n, n, 0, 1, 0, 1)) return fail(MI355CG_ERR_INVALID, "grid %d rejected", n);
+    if (world < 1 || rank < 0 || rank >= world || world > n - 1) return fail(MI355CG_ERR_INVALID, "bad world/rank %d/%d", rank, world);
+    // contiguous row slabs balanced by unknown count (bottom rows hold n/2-1 unknowns, upper rows n-1)
+    std::vector<int> first(world + 1);
+    first[0] = 1; first[world] = n;
+    for (int k = 1; k < world; ++k) {                         // smallest y with (unknowns in rows 1..y-1) >= k*U/world
+        const long long target = (gp.size * k + world / 2) / world;
+        int lo = 1, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (packed_row_begin(gp, mid) >= target) hi = mid; else lo = mid + 1; }
+        first[k] = lo;
+    }
+    for (int k = 1; k < world; ++k) first[k] = std::max(first[k], first[k - 1] + 1);        // every rank non-empty
+    for (int k = world - 1; k >= 1; --k) first[k] = std::min(first[k], first[k + 1] - 1);
+    const int a = first[rank], b = first[rank + 1] - 1;
+    if (y_lo) *y_lo = a;
+    if (y_hi) *y_hi = b;
+    return MI355CG_OK;
+}
+
+int mi355cg_owned_range(mi355cg_handle c, long long* packed_begin, long long* packed_len, int* y_lo, int* y_hi) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    if (packed_begin) *packed_begin = c->pk_begin;
+    if (packed_len) *packed_len = c->pk_len;
+    if (y_lo) *y_lo = c->g.y_lo;
+    if (y_hi) *y_hi = c->g.y_hi;
+    return MI355CG_OK;
+}
+
+static hipStream_t pick_stream(mi355cg_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream) {
+    if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (c->dtype != MI355CG_F64) return fail(MI355CG_ERR_INVALID, "slab mode is fp64 only");
+    if (prm->diagnostics) return fail(MI355CG_ERR_INVALID, "per-iteration diagnostics are not available in slab mode");
+    HIPCK(hipSetDevice(c->device));
+    c->dist_prm = *prm; c->dist_active = true;
+    const IterCfg cfg = make_cfg(prm);
+    if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
+    hipStream_t st = pick_stream(c, stream);
+    const size_t bytes = sizeof(double) * c->storage_len;
+    HIPCK(hipMemsetAsync(c->x, 0, bytes, st));
+    HIPCK(hipMemsetAsync(c->p[0], 0, bytes, st));
+    HIPCK(hipMemsetAsync(c->p[1], 0, bytes, st));
+    HIPCK(hipMemsetAsync(c->ap, 0, bytes, st));
+    HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, st));
+    c->cur = 0;
+    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, /*init=*/true, st, own_partA(c));
+    HIPCK(hipGetLastError());
+    c->solved = true;
+    return MI355CG_OK;
+}
+
+// which: 0 = stencil partials (fields FA_*), 1 = update partials (fields FB_*).  Reduces this rank's
+// partials into its sums buffer (device), which the caller all-gathers.
+int mi355cg_dist_reduce(mi355cg_handle c, int which, void* stream) {
+    if (!c || !c->dist_active) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run");
+    hipStream_t st = pick_stream(c, stream);
+    if (which == 0)
+        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, c->partA, c->nA_dist, c->strideA, (int)FA_COUNT, 0u, c->sumsA);
+    else
+        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, c->partB, c->grid_update, c->strideB, (int)FB_COUNT,
+                           (1u << FB_RMAX) | (1u << FB_DMAX) | (1u << FB_EMAX), c->sumsB);
+    HIPCK(hipGetLastError());
+    return MI355CG_OK;
+}
+int mi355cg_dist_sums_ptr(mi355cg_handle c, int which, void** dev_ptr, int* count) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    if (dev_ptr) *dev_ptr = which == 0 ? (void*)c->sumsA : (void*)c->sumsB;
+    if (count) *count = which == 0 ? (int)FA_COUNT : (int)FB_COUNT;
+    return MI355CG_OK;
+}
+
+// rows: 0 = whole slab, 1 = interior rows only, 2 = the first and last owned row (they read the
+// neighbours' ghost rows).  A full stencil phase is either {0} or {1, 2}; call mi355cg_dist_flip once after it.
+int mi355cg_dist_stencil(mi355cg_handle c, const double* gathered_B, int nranks, int rows, void* stream) {
+    if (!c || !c->dist_active || !gathered_B) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
+    const IterCfg cfg = make_cfg(&c->dist_prm);
+    StencilWhere w{pick_stream(c, stream), &c->wl, c->grid_stencil, 0};
+    if (rows == 1) w = StencilWhere{w.stream, &c->wl_int, c->grid_int, 0};
+    else if (rows == 2) w = StencilWhere{w.stream, &c->wl_edge, c->grid_edge, c->grid_int};
+    if (rows == 1 && c->wl_int.nitems == 0) return MI355CG_OK;
+    const PartSrc pb{gathered_B, nranks, 1, (int)FB_COUNT};
+    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, w, pb);
+    c->nA_dist = rows == 0 ? c->grid_stencil : c->grid_int + c->grid_edge;
+    HIPCK(hipGetLastError());
+    return MI355CG_OK;
+}
+int mi355cg_dist_flip(mi355cg_handle c) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    c->cur ^= 1;
+    return MI355CG_OK;
+}
+int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, void* stream) {
+    if (!c || !c->dist_active || !gathered_A) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
+    const IterCfg cfg = make_cfg(&c->dist_prm);
+    const PartSrc pa{gathered_A, nranks, 1, (int)FA_COUNT};
+    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, pick_stream(c, stream), pa);
+    HIPCK(hipGetLastError());
+    return MI355CG_OK;
+}
+// Asynchronous: after the stream reaches this point the summary is in pinned host memory.
+int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, void* stream) {
+    if (!c || !c->dist_active || !gathered_B) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
+    const IterCfg cfg = make_cfg(&c->dist_prm);
+    hipStream_t st = pick_stream(c, stream);
+    launch_check(c, cfg, st, PartSrc{gathered_B, nranks, 1, (int)FB_COUNT});
+    HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(c->hist_h, c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, st));
+    return MI355CG_OK;
+}
+int mi355cg_dist_summary(mi355cg_handle c, mi355cg_results* out, int* done) {
+    if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
+    const CgState fin = *c->summary_h;
+    const IterCfg cfg = make_cfg(&c->dist_prm);
+    mi355cg_results res{};
+    res.iterations = fin.it; res.converged = fin.converged; res.stop_reason = fin.reason;
+    res.final_residual_norm = fin.rmax;
+    res.final_precision = fin.it > 0 ? fin.dmax : DBL_MAX;
+    res.final_error_norm = cfg.has_u ? fin.emax : DBL_MAX;
+    res.r_norm2 = fin.rnorm2; res.initial_r_norm2 = fin.r0norm;
+    *out = res;
+    if (done) *done = fin.done;
+    return MI355CG_OK;
+}
+int mi355cg_dist_history(mi355cg_handle c, int iteration, double* precision, double* residual, double* error) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    const HistEntry& h = c->hist_h[((iteration % kHist) + kHist) % kHist];
+    if (precision) *precision = h.dmax;
+    if (residual) *residual = h.rmax;
+    if (error) *error = h.emax;
+    return MI355CG_OK;
+}
+// Boundary rows for the halo exchange.  vector: 0 = residual r, 1 = the CURRENT direction (the one
+// the last stencil wrote).  *_lo: row y_lo (send) and ghost row y_lo-1 (recv); *_hi: row y_hi and
+// ghost row y_hi+1.  Counts are in doubles (the full stored row, pads included).
+int mi355cg_dist_halo(mi355cg_handle c, int vector, void** send_lo, void** recv_lo, long long* n_lo,
+                      void** send_hi, void** recv_hi, long long* n_hi) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    double* v = vector == 0 ? c->r : c->p[c->cur];
+    const Geom& g = c->g;
+    auto row_ptr = [&](int y) { return v + (phys_start(g, y) - g.base0); };
+    auto row_len = [&](int y) -> long long { return y <= g.half ? g.Pb : g.Pu; };
+    if (send_lo) *send_lo = row_ptr(g.y_lo);
+    if (recv_lo) *recv_lo = row_ptr(g.y_lo - 1);
+    if (send_hi) *send_hi = row_ptr(g.y_hi);
+    if (recv_hi) *recv_hi = row_ptr(g.y_hi + 1);
+    // a message is the SENDER's row; the receiver's ghost row has the same global index, hence the same length
+    if (n_lo) *n_lo = row_len(g.y_lo);          // what this rank sends down; it receives row_len(y_lo-1)
+    if (n_hi) *n_hi = row_len(g.y_hi);          // what this rank sends up;   it receives row_len(y_hi+1)
+    return MI355CG_OK;
+}
+int mi355cg_dist_halo_recv_counts(mi355cg_handle c, long long* n_from_lo, long long* n_from_hi) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    const Geom& g = c->g;
+    if (n_from_lo) *n_from_lo = (g.y_lo - 1) <= g.half ? g.Pb : g.Pu;
+    if (n_from_hi) *n_from_hi = (g.y_hi + 1) <= g.half ? g.Pb : g.Pu;
     return MI355CG_OK;
 }
 

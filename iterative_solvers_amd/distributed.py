@@ -1,0 +1,353 @@
+"""Row-slab domain decomposition of the CG path across the GPUs of one node: one process per
+GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI) for the two things that cross ranks.
+
+The reference is single-process (no collectives anywhere); this module is the
+scaling surface around the same kernels.  Per CG iteration and rank:
+
+    stencil (interior rows)      -- overlaps the halo messages still in flight
+    wait halos ; stencil (first + last owned row) ; direction buffers flip
+    all_gather  {(Ap,p), (r,p)}  of every rank        -> alpha on every rank, in rank order
+    isend/irecv boundary rows of the new direction    -- overlaps the update kernel
+    update x, r
+    all_gather  {r.r, max|r|, max|dx|, max|x-u|, ...} -> beta + stop decision on every rank
+    isend/irecv boundary rows of r                    -- overlaps the next interior stencil
+
+Each rank reduces the gathered per-rank sums in rank order inside the consumer kernel's
+prologue, so all ranks compute bit-identical alpha/beta and take the same stop decision without
+any host round trip; the host polls a pinned summary every `sync_every` iterations.
+
+`SlabEngine` is the compute side (HIP kernels through the C ABI).  The driver only needs the
+small engine protocol below, which is what the CPU `gloo` tests exercise with a test double.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _capi
+from .solver import default_params
+
+FA_COUNT, FB_COUNT = 2, 6          # fields of the stencil / update partial sums (cg_kernels.h)
+
+
+def slab_rows(n: int, world: int, rank: int):
+    """Owned grid rows [y_lo, y_hi] of `rank`: contiguous slabs balanced by unknown count."""
+    lo, hi = C.c_int(), C.c_int()
+    _capi.check(_capi.load().mi355cg_slab_rows(n, world, rank, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+class _DevView:
+    """Zero-copy torch view of device memory owned by libmi355cg (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def _view(ptr: int, count: int, device) -> torch.Tensor:
+    return torch.as_tensor(_DevView(ptr, count), device=device)
+
+
+class SlabEngine:
+    """One rank's slab on one GPU: thin wrapper over the mi355cg_dist_* C ABI."""
+
+    def __init__(self, n: int, y_lo: int, y_hi: int, device: int = 0,
+                 domain=(1.0, 2.0, 1.0, 2.0)):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        a, b, c, d = domain
+        rc = self._lib.mi355cg_create_slab(n, n, a, b, c, d, _capi.F64, device, y_lo, y_hi, C.byref(self._h))
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(self._lib.mi355cg_last_error().decode())
+        _capi.check(rc)
+        self.n, self.y_lo, self.y_hi = n, y_lo, y_hi
+        self.device = torch.device("cuda", device)
+        pb, pl = C.c_longlong(), C.c_longlong()
+        _capi.check(self._lib.mi355cg_owned_range(self._h, C.byref(pb), C.byref(pl), None, None))
+        self.packed_begin, self.packed_len = pb.value, pl.value
+        self._sums = {}
+        self._halo_cache = {}
+        for which in (0, 1):
+            p, cnt = C.c_void_p(), C.c_int()
+            _capi.check(self._lib.mi355cg_dist_sums_ptr(self._h, which, C.byref(p), C.byref(cnt)))
+            self._sums[which] = _view(p.value, cnt.value, self.device)
+
+    def close(self):
+        if self._h:
+            self._lib.mi355cg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    # -- engine protocol ----------------------------------------------------------------------
+    def begin(self, params: _capi.Params):
+        _capi.check(self._lib.mi355cg_dist_begin(self._h, C.byref(params), self._stream()))
+
+    def reduce(self, which: int):
+        _capi.check(self._lib.mi355cg_dist_reduce(self._h, which, self._stream()))
+
+    def sums(self, which: int) -> torch.Tensor:
+        return self._sums[which]
+
+    def stencil(self, gathered_b: torch.Tensor, rows: int = 0):
+        _capi.check(self._lib.mi355cg_dist_stencil(self._h, gathered_b.data_ptr(), gathered_b.numel() // FB_COUNT,
+                                                   rows, self._stream()))
+
+    def flip(self):
+        _capi.check(self._lib.mi355cg_dist_flip(self._h))
+
+    def update(self, gathered_a: torch.Tensor):
+        _capi.check(self._lib.mi355cg_dist_update(self._h, gathered_a.data_ptr(), gathered_a.numel() // FA_COUNT,
+                                                  self._stream()))
+
+    def check(self, gathered_b: torch.Tensor):
+        _capi.check(self._lib.mi355cg_dist_check(self._h, gathered_b.data_ptr(), gathered_b.numel() // FB_COUNT,
+                                                 self._stream()))
+
+    def summary(self):
+        torch.cuda.current_stream().synchronize()
+        res, done = _capi.Results(), C.c_int()
+        _capi.check(self._lib.mi355cg_dist_summary(self._h, C.byref(res), C.byref(done)))
+        return res, bool(done.value)
+
+    def history(self, it: int):
+        p, r, e = C.c_double(), C.c_double(), C.c_double()
+        _capi.check(self._lib.mi355cg_dist_history(self._h, it, C.byref(p), C.byref(r), C.byref(e)))
+        return p.value, r.value, e.value
+
+    def halo(self, vector: int):
+        """Boundary rows of vector (0 = r, 1 = current direction) as tensor views."""
+        sl, rl, sh, rh = (C.c_void_p() for _ in range(4))
+        nl, nh, fl, fh = (C.c_longlong() for _ in range(4))
+        _capi.check(self._lib.mi355cg_dist_halo(self._h, vector, C.byref(sl), C.byref(rl), C.byref(nl),
+                                                C.byref(sh), C.byref(rh), C.byref(nh)))
+        key = (sl.value, rl.value, sh.value, rh.value)
+        if key in self._halo_cache:
+            return self._halo_cache[key]
+        _capi.check(self._lib.mi355cg_dist_halo_recv_counts(self._h, C.byref(fl), C.byref(fh)))
+        self._halo_cache[key] = {"send_lo": _view(sl.value, nl.value, self.device), "recv_lo": _view(rl.value, fl.value, self.device),
+                "send_hi": _view(sh.value, nh.value, self.device), "recv_hi": _view(rh.value, fh.value, self.device)}
+        return self._halo_cache[key]
+
+    def _owned(self, fn) -> np.ndarray:
+        out = np.empty(self.packed_len)
+        _capi.check(fn(self._h, out))
+        return out
+
+    def solution(self): return self._owned(self._lib.mi355cg_get_solution)
+    def rhs(self): return self._owned(self._lib.mi355cg_get_rhs)
+    def true_solution(self): return self._owned(self._lib.mi355cg_get_true_solution)
+    def recursive_residual(self): return self._owned(self._lib.mi355cg_get_recursive_residual)
+
+
+# ---------------------------------------------------------------------------------------------
+class _Comm:
+    """The two communication patterns, over whatever backend the process group has.  With
+    "nccl" (RCCL) device tensors go straight to the collectives; with "gloo" (CPU tests, or
+    several ranks sharing one GPU) device tensors are staged through host memory."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.stage = self.backend == "gloo"
+
+    def all_gather(self, out: torch.Tensor, local: torch.Tensor):
+        if self.world == 1:
+            out.copy_(local)
+            return
+        if self.stage and local.is_cuda:
+            loc = local.cpu()
+            parts = [torch.empty_like(loc) for _ in range(self.world)]
+            dist.all_gather(parts, loc, group=self.group)
+            out.copy_(torch.cat(parts).to(out.device))
+        elif self.stage:
+            parts = list(out.view(self.world, -1).unbind(0))
+            dist.all_gather(parts, local, group=self.group)
+        else:
+            dist.all_gather_into_tensor(out, local, group=self.group)
+
+    def halo_start(self, h: dict):
+        """Exchange boundary rows with rank-1 / rank+1.  Returns a token for halo_wait."""
+        if self.world == 1:
+            return None
+        lo, hi = self.rank - 1, self.rank + 1
+        if self.stage:
+            reqs, post = [], []
+            for peer, send, recv in ((lo, "send_lo", "recv_lo"), (hi, "send_hi", "recv_hi")):
+                if 0 <= peer < self.world:
+                    s = h[send].cpu() if h[send].is_cuda else h[send]
+                    r = torch.empty(h[recv].numel(), dtype=h[recv].dtype)
+                    reqs.append(dist.isend(s.contiguous(), peer, group=self.group))
+                    reqs.append(dist.irecv(r, peer, group=self.group))
+                    post.append((h[recv], r))
+            return ("staged", reqs, post)
+        ops = []
+        for peer, send, recv in ((lo, "send_lo", "recv_lo"), (hi, "send_hi", "recv_hi")):
+            if 0 <= peer < self.world:
+                ops.append(dist.P2POp(dist.isend, h[send], peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, h[recv], peer, self.group))
+        return ("nccl", dist.batch_isend_irecv(ops)) if ops else None
+
+    @staticmethod
+    def halo_wait(token):
+        if token is None:
+            return
+        if token[0] == "staged":
+            for r in token[1]:
+                r.wait()
+            for dst, src in token[2]:
+                dst.copy_(src.to(dst.device))
+        else:
+            for r in token[1]:
+                r.wait()                      # stream-level wait for NCCL: the host does not block
+
+
+@dataclass
+class DistResults:
+    iterations: int
+    converged: bool
+    stop_reason: int
+    final_residual_norm: float
+    final_precision: float
+    final_error_norm: float
+    r_norm2: float
+    initial_r_norm2: float
+    seconds: float
+
+
+class DistributedCG:
+    """CG over row slabs.  `engine` implements the SlabEngine protocol."""
+
+    def __init__(self, engine, group=None, overlap: bool = True):
+        self.eng = engine
+        self.comm = _Comm(group)
+        self.overlap = overlap
+        dev = engine.sums(0).device
+        self.gA = torch.zeros(self.comm.world * FA_COUNT, dtype=torch.float64, device=dev)
+        self.gB = torch.zeros(self.comm.world * FB_COUNT, dtype=torch.float64, device=dev)
+
+    def _gather(self, which: int):
+        self.eng.reduce(which)
+        self.comm.all_gather(self.gA if which == 0 else self.gB, self.eng.sums(which))
+
+    def solve(self, params: _capi.Params, callback=None) -> DistResults:
+        eng, comm = self.eng, self.comm
+        msg = params.rule == _capi.RULE_MSG_MAXNORM
+        t0 = time.perf_counter()
+        eng.begin(params)                                   # x = 0, r = b, p = 0 ; partial norms of r0
+        self._gather(1)
+        tok_r = comm.halo_start(eng.halo(0))                # ghost rows of r0 = b
+        tok_p = None                                        # direction is 0 everywhere: ghosts already right
+        eng.check(self.gB)
+        res, done = eng.summary()
+        if msg and callback:
+            callback(0, res.final_precision, res.final_residual_norm, res.final_error_norm)
+        sync_every = params.sync_every if params.sync_every > 0 else (100 if msg else 200)
+        sync_every = min(sync_every, 512)
+        every = params.callback_every
+        it_done = 0
+        while not done:
+            m = min(sync_every, max(1, params.max_iterations - it_done))
+            if msg and every > 0:
+                m = min(m, every - it_done % every)
+            for _ in range(m):
+                if self.overlap and comm.world > 1:
+                    eng.stencil(self.gB, rows=1)            # interior rows: no ghost needed
+                    comm.halo_wait(tok_r); comm.halo_wait(tok_p)
+                    eng.stencil(self.gB, rows=2)            # first + last owned row
+                else:
+                    comm.halo_wait(tok_r); comm.halo_wait(tok_p)
+                    eng.stencil(self.gB, rows=0)
+                eng.flip()
+                self._gather(0)
+                tok_p = comm.halo_start(eng.halo(1))        # new direction's boundary rows (overlaps the update)
+                eng.update(self.gA)
+                self._gather(1)
+                tok_r = comm.halo_start(eng.halo(0))        # r's boundary rows (overlaps the next interior stencil)
+            eng.check(self.gB)
+            res, done = eng.summary()
+            if msg and callback:
+                for it in range(it_done + 1, res.iterations + 1):
+                    stopped_here = done and res.stop_reason != _capi.STOP_ITERATIONS and it == res.iterations
+                    if (it == 1 or (every > 0 and it % every == 0)) and not stopped_here:
+                        callback(it, *eng.history(it))
+            it_done = res.iterations
+        comm.halo_wait(tok_r); comm.halo_wait(tok_p)
+        if msg and callback:
+            callback(res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm)
+        return DistResults(res.iterations, bool(res.converged), res.stop_reason, res.final_residual_norm,
+                           res.final_precision, res.final_error_norm, res.r_norm2, res.initial_r_norm2,
+                           time.perf_counter() - t0)
+
+
+# ---------------------------------------------------------------------------------------------
+def weak_scaling_n(n1: int, world: int) -> int:
+    """Grid size whose unknown count is ~world x that of n1 (even)."""
+    n = int(round(n1 * (world ** 0.5) / 2.0)) * 2
+    return max(n, 6)
+
+
+def bench(args, rule: int) -> dict:
+    """bench.py's N > 1 leg: weak scaling, every rank owns ~ the config-2 number of unknowns."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n = weak_scaling_n(args.n, world)
+    U1 = (args.n // 2 - 1) * (3 * args.n // 2 - 1)
+    U = (n // 2 - 1) * (3 * n // 2 - 1)
+    y_lo, y_hi = slab_rows(n, world, rank)
+    eng = SlabEngine(n, y_lo, y_hi, device=local_rank)
+    cg = DistributedCG(eng, overlap=True)
+
+    def run(iters):
+        p = default_params(rule)
+        p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = iters, 1, 0, 0, 500
+        return cg.solve(p)
+
+    run(args.warmup)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    res = run(args.steps)
+    torch.cuda.synchronize(); dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=eng.device)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    assert res.iterations == args.steps
+    its = args.steps / dt
+    slab_units = U / U1                                     # config-2-sized slabs advanced per iteration
+    out = {
+        "metric": "cg_iters_per_sec", "value": round(its * slab_units, 2), "unit": "iters/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson fp64 over {world} row slabs of ~{U1} unknowns "
+                               f"(config-2 size per GPU), matrix-free CG, fixed {args.steps} iterations",
+                   "n": n, "unknowns": U, "unknowns_per_gpu": U / world, "rule": args.rule,
+                   "value_is": "global CG iterations/s x (unknowns / config-2 unknowns) = config-2-sized slab iterations/s",
+                   "parallelism": f"row-slab x{world}, RCCL all_gather + isend/irecv halos"},
+        "global_iters_per_sec": round(its, 2),
+        "hbm_gbps": round(88.0 * U * its / 1e9, 1),
+        "hbm_frac_of_8TBps": round(88.0 * U * its / 1e9 / (8000.0 * world), 4),
+    }
+    dist.barrier()
+    return out

@@ -1,0 +1,186 @@
+"""TEST DOUBLE for iterative_solvers_amd.distributed.SlabEngine: the same engine protocol, computed
+on the CPU with the oracle's operator.  It exists so that the distributed DRIVER (slab partition,
+halo exchange order, all-gather of per-rank sums, rank-ordered reduction, stop decisions,
+callback cadence) can be exercised with world_size > 1 on `gloo` without a GPU.  It lives under
+tests/ and is never importable from the product package.
+
+Semantics mirrored from iterative_solvers_amd/csrc/cg_kernels.h: fused direction update inside
+the stencil phase with ping-pong direction buffers, ghost rows for r and the direction,
+per-rank sums all-gathered and reduced in rank order, decision taken in the stencil prologue.
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+import torch
+
+from oracle.oracle import OracleGrid
+
+DBL_MAX = sys.float_info.max
+RULE_MSG, RULE_REL2 = 0, 1
+FA_COUNT, FB_COUNT = 2, 6
+FB_RR, FB_RMAX, FB_DMAX, FB_EMAX, FB_D2, FB_E2 = range(6)
+
+
+class _Res:
+    pass
+
+
+class OracleSlabEngine:
+    def __init__(self, n: int, y_lo: int, y_hi: int):
+        self.n, self.half, self.y_lo, self.y_hi = n, n // 2, y_lo, y_hi
+        self.og = OracleGrid(n, n, 1.0, 2.0, 1.0, 2.0)
+        self.U = self.og.size
+        self.bottom = (self.half - 1) * self.half
+        self.own = slice(self.row_begin(y_lo), self.row_begin(y_hi + 1))
+        self.packed_begin, self.packed_len = self.own.start, self.own.stop - self.own.start
+        self.b = np.zeros(self.U); self.b[self.own] = self.og.rhs()[self.own]
+        self.u = np.zeros(self.U); self.u[self.own] = self.og.true_solution()[self.own]
+        self._sums = {0: torch.zeros(FA_COUNT, dtype=torch.float64), 1: torch.zeros(FB_COUNT, dtype=torch.float64)}
+
+    # rows 1..n-1 hold unknowns; row_begin(n) = U
+    def row_begin(self, y: int) -> int:
+        y = min(max(y, 1), self.n)
+        return (self.half - 1) * (y - 1) if y <= self.half else self.bottom + (y - self.half - 1) * (self.n - 1)
+
+    def rows(self, ya: int, yb: int) -> slice:
+        return slice(self.row_begin(ya), self.row_begin(yb + 1))
+
+    # -- protocol ---------------------------------------------------------------------------------
+    def begin(self, params):
+        self.prm = params
+        z = lambda: np.zeros(self.U)
+        self.x, self.r, self.p, self.ap = z(), z(), [z(), z()], z()
+        self.r[self.own] = self.b[self.own]
+        self.cur = 0
+        self.state = dict(it=0, done=0, reason=0, converged=0, first=1, rr=0.0, rz=0.0, r0norm=0.0,
+                          rnorm2=0.0, rmax=0.0, dmax=0.0, emax=0.0)
+        self.use_u = params.rule == RULE_MSG and params.use_true_solution
+        self.partA = np.zeros((2, FA_COUNT))            # [interior | edge] x fields
+        self.hist = {}
+        self._update_partials(self.x[self.own], self.x[self.own])
+
+    def _update_partials(self, xn, x0):
+        r = self.r[self.own]
+        d = xn - x0
+        e = xn - self.u[self.own] if self.use_u else np.zeros(1)
+        self.partB = np.array([np.dot(r, r), np.abs(r).max(initial=0.0), np.abs(d).max(initial=0.0),
+                               np.abs(e).max(initial=0.0), np.dot(d, d), np.dot(e, e)])
+
+    def reduce(self, which: int):
+        if which == 0:
+            self._sums[0][:] = torch.from_numpy(self.partA.sum(axis=0))
+        else:
+            self._sums[1][:] = torch.from_numpy(self.partB)
+
+    def sums(self, which: int) -> torch.Tensor:
+        return self._sums[which]
+
+    def _decide(self, gathered_b: torch.Tensor):
+        g = gathered_b.numpy().reshape(-1, FB_COUNT)
+        rr = 0.0
+        for k in range(g.shape[0]):                      # rank order
+            rr += g[k, FB_RR]
+        rmax, dmax, emax = g[:, FB_RMAX].max(), g[:, FB_DMAX].max(), g[:, FB_EMAX].max()
+        s, p = self.state, self.prm
+        rnorm2 = np.sqrt(rr)
+        r0 = rnorm2 if s["first"] else s["r0norm"]
+        done = reason = conv = 0
+        beta = 0.0
+        if p.rule == RULE_REL2:
+            go = s["it"] < p.max_iterations and (p.fixed_iterations or rnorm2 > p.eps_rel * r0)
+            if not go:
+                done, conv = 1, int(rnorm2 <= p.eps_rel * r0)
+            if not s["first"]:
+                beta = rr / s["rr"]
+        else:
+            if s["it"] >= 1 and not p.fixed_iterations:
+                if p.eps_precision > 0 and dmax < p.eps_precision: done, conv, reason = 1, 1, 1
+                elif p.eps_residual > 0 and rmax < p.eps_residual: done, conv, reason = 1, 1, 2
+                elif p.eps_exact_error > 0 and self.use_u and emax < p.eps_exact_error: done, conv, reason = 1, 1, 3
+            if not done and not (s["it"] < p.max_iterations):
+                done = 1
+            if not s["first"]:
+                beta = (rnorm2 * rnorm2) / s["rz"]
+        out = dict(s, rr=rr, rnorm2=rnorm2, r0norm=r0, rmax=rmax, dmax=dmax, emax=emax, done=done, reason=reason,
+                   converged=conv, beta=beta)
+        self.hist[s["it"]] = (dmax, rmax, emax)
+        return out
+
+    def stencil(self, gathered_b: torch.Tensor, rows: int = 0):
+        if self.state["done"]:
+            return
+        d = self._decide(gathered_b)
+        self._pending = d
+        if d["done"]:
+            if rows in (0, 2):
+                self.state = d
+            return
+        beta = d["beta"]
+        pin, pout = self.p[self.cur], self.p[self.cur ^ 1]
+        halo = self.rows(max(self.y_lo - 1, 1), min(self.y_hi + 1, self.n - 1))
+        pn = np.zeros(self.U)
+        pn[halo] = self.r[halo] + beta * pin[halo]       # owned + ghost rows; everything else is not read
+        apn = self.og.apply(pn)
+        if rows == 0:
+            sel = [self.rows(self.y_lo, self.y_hi)]
+        elif rows == 1:
+            sel = [self.rows(self.y_lo + 1, self.y_hi - 1)] if self.y_hi - self.y_lo >= 2 else []
+        else:
+            sel = [self.rows(self.y_lo, self.y_lo)] + ([self.rows(self.y_hi, self.y_hi)] if self.y_hi > self.y_lo else [])
+        slot = 1 if rows == 2 else 0
+        if rows != 2:
+            self.partA[:] = 0.0
+        acc = np.zeros(FA_COUNT)
+        for sl in sel:
+            pout[sl] = pn[sl]
+            self.ap[sl] = apn[sl]
+            acc += (np.dot(apn[sl], pn[sl]), np.dot(self.r[sl], pn[sl]))
+        self.partA[slot] = acc
+        if rows in (0, 2):
+            self.state = dict(d)
+
+    def flip(self):
+        self.cur ^= 1
+
+    def update(self, gathered_a: torch.Tensor):
+        s = self.state
+        if s["done"]:
+            return
+        g = gathered_a.numpy().reshape(-1, FA_COUNT)
+        pap = rz = 0.0
+        for k in range(g.shape[0]):
+            pap += g[k, 0]; rz += g[k, 1]
+        alpha = (rz / pap) if self.prm.rule == RULE_MSG else (s["rr"] / pap)
+        o = self.own
+        x0 = self.x[o].copy()
+        self.x[o] = x0 + alpha * self.p[self.cur][o]
+        self.r[o] = self.r[o] - alpha * self.ap[o]
+        self._update_partials(self.x[o], x0)
+        s.update(it=s["it"] + 1, first=0, rz=rz)
+
+    def check(self, gathered_b: torch.Tensor):
+        self._summary = dict(self.state) if self.state["done"] else self._decide(gathered_b)
+
+    def summary(self):
+        s = self._summary
+        res = _Res()
+        res.iterations, res.converged, res.stop_reason = s["it"], s["converged"], s["reason"]
+        res.final_residual_norm = s["rmax"]
+        res.final_precision = s["dmax"] if s["it"] > 0 else DBL_MAX
+        res.final_error_norm = s["emax"] if self.use_u else DBL_MAX
+        res.r_norm2, res.initial_r_norm2 = s["rnorm2"], s["r0norm"]
+        return res, bool(s["done"])
+
+    def history(self, it: int):
+        d, r, e = self.hist[it]
+        return d, r, (e if self.use_u else DBL_MAX)
+
+    def halo(self, vector: int):
+        v = self.r if vector == 0 else self.p[self.cur]
+        t = lambda ya: torch.from_numpy(v[self.rows(ya, ya)]) if 1 <= ya <= self.n - 1 else torch.zeros(0, dtype=torch.float64)
+        return {"send_lo": t(self.y_lo), "recv_lo": t(self.y_lo - 1), "send_hi": t(self.y_hi), "recv_hi": t(self.y_hi + 1)}
+
+    def solution(self):
+        return self.x[self.own].copy()

@@ -1,0 +1,96 @@
+"""world_size-2/3 `gloo` tests of the distributed CG DRIVER (iterative_solvers_amd.distributed.
+DistributedCG) on the CPU.  The compute engine is the oracle-backed test double in
+tests/slab_oracle_engine.py; what is under test is the product's orchestration: slab partition,
+halo exchange (who sends which row to whom, and when), all-gather of per-rank sums, identical
+decisions on every rank, callback cadence, overlap ordering."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, rule, overlap, outdir, eps_kw):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from iterative_solvers_amd import _capi
+        from iterative_solvers_amd.distributed import DistributedCG, slab_rows
+        from iterative_solvers_amd.solver import default_params
+        from slab_oracle_engine import OracleSlabEngine
+        y_lo, y_hi = slab_rows(n, world, rank)
+        eng = OracleSlabEngine(n, y_lo, y_hi)
+        cg = DistributedCG(eng, overlap=overlap)
+        p = default_params(rule)
+        for k, v in eps_kw.items():
+            setattr(p, k, v)
+        cbs = []
+        res = cg.solve(p, callback=lambda *a: cbs.append(a))
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), x=eng.solution(), begin=eng.packed_begin,
+                 it=res.iterations, reason=res.stop_reason, conv=res.converged, rmax=res.final_residual_norm,
+                 rnorm2=res.r_norm2, cbs=np.array(cbs, dtype=float).reshape(-1, 4))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, n, rule, overlap, **eps_kw):
+    port = 29000 + (os.getpid() * 7 + world * 131 + n) % 2000
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, port, n, rule, overlap, d, eps_kw), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+        parts = [{k: p[k] for k in p.files} for p in parts]
+    x = np.concatenate([p["x"] for p in parts])
+    assert [int(p["begin"]) for p in parts] == list(np.cumsum([0] + [len(p["x"]) for p in parts[:-1]]))
+    for p in parts[1:]:                                           # every rank took the same decisions
+        assert int(p["it"]) == int(parts[0]["it"]) and int(p["reason"]) == int(parts[0]["reason"])
+        assert np.array_equal(p["cbs"], parts[0]["cbs"])
+    return x, parts[0]
+
+
+@pytest.mark.parametrize("world,overlap", [(2, True), (2, False), (3, True)])
+def test_rel2norm_two_and_three_ranks_match_the_oracle(world, overlap):
+    from oracle.oracle import OracleGrid
+    n = 32
+    ref = OracleGrid(n, n).mf_solve(eps=1e-8, max_iterations=10 ** 5)
+    x, r0 = _run(world, n, 1, overlap, eps_rel=1e-8, max_iterations=10 ** 5)
+    assert int(r0["it"]) == ref.iterations and bool(r0["conv"])
+    assert np.abs(x - ref.x).max() <= 1e-10 * np.abs(ref.x).max()
+    assert abs(float(r0["rnorm2"]) - ref.r_norm) / ref.initial_r_norm <= 1e-12
+
+
+def test_msg_rule_callbacks_and_stop_reason_two_ranks():
+    from oracle.oracle import OracleGrid
+    n = 24
+    ref = OracleGrid(n, n).msg_solve(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
+    x, r0 = _run(2, n, 0, True, eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, callback_every=10)
+    assert (int(r0["it"]), int(r0["reason"])) == (ref.iterations, ref.stop_reason)
+    its = [int(c[0]) for c in r0["cbs"]]
+    want = [0, 1] + [i for i in range(10, ref.iterations + 1, 10) if i != ref.iterations or False] + [ref.iterations]
+    if ref.iterations % 10 == 0:                                   # no periodic callback on the stopping iteration
+        want = [0, 1] + list(range(10, ref.iterations, 10)) + [ref.iterations]
+    assert its == want
+    assert np.abs(x - ref.x).max() <= 1e-10 * np.abs(ref.x).max()
+    assert abs(float(r0["rmax"]) - ref.final_residual_norm) / ref.initial_r_norm2 <= 1e-12
+
+
+def test_slab_partition_covers_grid_and_balances():
+    sys.path.insert(0, ROOT)
+    from iterative_solvers_amd.distributed import slab_rows, weak_scaling_n
+    for n, world in ((4096, 2), (4096, 4), (16384, 4), (32768, 8), (8, 3), (6, 5), (64, 7)):
+        rows = [slab_rows(n, world, r) for r in range(world)]
+        assert rows[0][0] == 1 and rows[-1][1] == n - 1
+        assert all(rows[k][1] + 1 == rows[k + 1][0] for k in range(world - 1))
+        assert all(lo <= hi for lo, hi in rows)
+        if n >= 4096:
+            half = n // 2
+            cnt = [sum((half - 1) if y <= half else (n - 1) for y in range(lo, hi + 1)) for lo, hi in rows]
+            assert max(cnt) / min(cnt) < 1.01
+    assert [weak_scaling_n(4096, p) for p in (1, 2, 4, 8)] == [4096, 5792, 8192, 11586]
