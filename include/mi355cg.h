@@ -136,7 +136,8 @@ int  mi355cg_get_layout(mi355cg_handle h, long long *padded_len, int *pitch_bott
  * moves the two things that cross ranks each phase: ghost rows (mi355cg_dist_halo) and the
  * per-rank reduced partials (mi355cg_dist_sums_ptr -> all_gather -> gathered_* arguments).
  * Every rank reduces the gathered partials in rank order, so all ranks take identical decisions.
- * All dist calls are asynchronous on `stream` (NULL = the context's own stream).
+ * All dist calls are asynchronous on `stream`, a hipStream_t taken literally (NULL = HIP's default
+ * stream, which is torch's default stream too), so they order with the caller's collectives.
  * Host vectors of a slab context (get_rhs, get_solution, ...) cover only its owned packed range. */
 int  mi355cg_slab_rows(int n, int world, int rank, int *y_lo, int *y_hi);
 int  mi355cg_create_slab(int n, int m, double a, double b, double c, double d, int dtype, int device,

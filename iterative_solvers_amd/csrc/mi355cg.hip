@@ -295,6 +295,7 @@ IterCfg make_cfg(const mi355cg_params* prm) {
 
 template <typename T>
 int upload_packed(mi355cg_ctx* c, const double* host_packed, T* storage) {
+    if (c->is_slab) HIPCK(hipDeviceSynchronize());
     HIPCK(hipMemcpyAsync(c->packed, host_packed, sizeof(double) * c->pk_len, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL((k_unpack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), c->packed, storage);
     HIPCK(hipGetLastError());
@@ -303,6 +304,7 @@ int upload_packed(mi355cg_ctx* c, const double* host_packed, T* storage) {
 }
 template <typename T>
 int download_packed(mi355cg_ctx* c, const T* storage, double* host_packed) {
+    if (c->is_slab) HIPCK(hipDeviceSynchronize());      // slab phases run on the caller's streams
     hipLaunchKernelGGL((k_pack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), storage, c->packed);
     HIPCK(hipGetLastError());
     HIPCK(hipMemcpyAsync(host_packed, c->packed, sizeof(double) * c->pk_len, hipMemcpyDeviceToHost, c->stream));
@@ -677,7 +679,9 @@ int mi355cg_owned_range(mi355cg_handle c, long long* packed_begin, long long* pa
     return MI355CG_OK;
 }
 
-static hipStream_t pick_stream(mi355cg_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+// The dist entry points enqueue on the caller's stream, taken literally (NULL = HIP's default stream,
+// which is also torch's default stream), so they order with the caller's collectives and copies.
+static hipStream_t pick_stream(mi355cg_ctx*, void* stream) { return (hipStream_t)stream; }
 
 int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream) {
     if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
