@@ -1,0 +1,71 @@
+// compat_driver.cpp -- exercises the C++ drop-in headers the way the reference's own callers do
+// (solver/main.cpp:596-712 flow, the Qt worker's DirichletSolver flow qt_gui/src/mainwindow.cpp:55-68,
+// 290-304, and the matrix-free pair).  Prints one JSON object; tests/test_gpu_cpp_compat.py compares it
+// with the CPU oracle.  Build: g++ -std=c++17 -I iterative_solvers_amd/compat compat_driver.cpp -L... -lmi355cg
+#include "dirichlet_solver.hpp"
+#include "matrix_free_system.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+
+static void jvec(const char* key, const std::vector<double>& v, bool last = false) {
+    std::printf("\"%s\": [", key);
+    for (size_t i = 0; i < v.size(); ++i) std::printf("%s%.17g", i ? ", " : "", v[i]);
+    std::printf("]%s\n", last ? "" : ",");
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? std::atoi(argv[1]) : 16;
+    const int max_it = argc > 2 ? std::atoi(argv[2]) : 10000;
+    Kokkos::initialize();
+    std::printf("{\n");
+    {   // solver/main.cpp flow: GridSystem -> MSGSolver(matrix, rhs, eps, maxIt) -> solve(u) -> spmv residual
+        GridSystem grid(N, N, 1.0, 2.0, 1.0, 2.0);
+        KokkosVector u = grid.get_true_solution_vector();
+        MSGSolver solver(grid.get_matrix(), grid.get_rhs(), 1e-9, max_it);
+        solver.setVerbose(false);
+        std::vector<double> cb_its;
+        solver.setIterationCallback([&](int it, double, double, double) { cb_its.push_back(it); });
+        KokkosVector x = solver.solve(u);
+        const int n = (int)grid.get_rhs().extent(0);
+        KokkosVector Ax("Ax", n);
+        KokkosSparse::spmv("N", 1.0, grid.get_matrix(), x, 0.0, Ax);
+        std::vector<double> xs(x.data(), x.data() + n), res(n);
+        for (int i = 0; i < n; ++i) res[i] = Ax(i) - grid.get_rhs()(i);
+        std::printf("\"msg_iterations\": %d, \"msg_converged\": %d, \"msg_reason\": %d, \"msg_rmax\": %.17g, \"msg_nnz\": %lld,\n",
+                    solver.getIterations(), solver.hasConverged() ? 1 : 0, (int)solver.getStopReason(),
+                    solver.getFinalResidualNorm(), grid.get_matrix().nnz());
+        jvec("msg_x", xs); jvec("msg_residual", res); jvec("msg_cb_its", cb_its);
+        auto nc = grid.get_node_coordinates(0);
+        std::printf("\"node0\": [%.17g, %.17g],\n", nc.x, nc.y);
+    }
+    {   // Qt worker flow
+        DirichletSolver ds(N, N, 1.0, 2.0, 1.0, 2.0);
+        ds.setVerbose(false);
+        ds.setSolverParameters(1e-8, 1e-8, 1e-8, max_it);
+        int completions = 0;
+        ds.setCompletionCallback([&](const SolverResults&) { ++completions; });
+        SolverResults r = ds.solve();
+        std::printf("\"ds_iterations\": %d, \"ds_converged\": %d, \"ds_residual_norm\": %.17g, \"ds_error_norm\": %.17g, \"ds_completions\": %d,\n",
+                    r.iterations, r.converged ? 1 : 0, r.residual_norm, r.error_norm, completions);
+        jvec("ds_solution", r.solution); jvec("ds_residual", r.residual); jvec("ds_error", r.error);
+        const bool saved = ds.saveResultsToFile("/tmp/mi355cg_compat_results.txt") && ds.saveMatrixAndRhsToFile("/tmp/mi355cg_compat_matrix.txt");
+        std::printf("\"ds_saved\": %d, \"ds_method\": \"%s\",\n", saved ? 1 : 0, ds.getMethodName().empty() ? "" : "set");
+    }
+    {   // matrix-free pair
+        MatrixFreeSystem sys(N, N, 1.0, 2.0, 1.0, 2.0);
+        std::vector<double> ones(sys.size(), 1.0), y;
+        sys.apply(ones, y);
+        MatrixFreeSolver mf(sys, sys.get_rhs(), 1e-8, 1000000);
+        int done_ok = -1;
+        mf.setCompletionCallback([&](bool ok, const std::string&) { done_ok = ok ? 1 : 0; });
+        std::vector<double> x = mf.solve(sys.get_true_solution_vector());
+        std::printf("\"mf_iterations\": %d, \"mf_completed_ok\": %d,\n", mf.getIterations(), done_ok);
+        jvec("mf_apply_ones", y); jvec("mf_x", x, true);
+    }
+    std::printf("}\n");
+    bool threw = false;
+    try { GridSystem bad(7, 7, 1.0, 2.0, 1.0, 2.0); } catch (const std::invalid_argument&) { threw = true; }
+    Kokkos::finalize();
+    return threw ? 0 : 3;
+}
