@@ -83,7 +83,7 @@ def main():
     torch.cuda.set_device(local_rank)
     rule = _capi.RULE_REL_2NORM if args.rule == "rel2" else _capi.RULE_MSG_MAXNORM
 
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1":
         from iterative_solvers_amd import distributed as dist_cg
         out = dist_cg.bench(args, rule)
         if rank == 0:

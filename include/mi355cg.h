@@ -133,8 +133,9 @@ int  mi355cg_get_layout(mi355cg_handle h, long long *padded_len, int *pitch_bott
  * The reference is single-process (no collectives exist in it); this is the scaling
  * surface.  The grid is cut into row slabs balanced by unknown count.  The library runs the
  * kernels; the caller (iterative_solvers_amd/distributed.py over torch.distributed = RCCL)
- * moves the two things that cross ranks each phase: ghost rows (mi355cg_dist_halo) and the
- * per-rank reduced partials (mi355cg_dist_sums_ptr -> all_gather -> gathered_* arguments).
+ * moves what crosses ranks each phase: the per-rank record = reduced partials, optionally followed
+ * by the rank's two boundary rows (mi355cg_dist_sums_ptr -> all_gather -> gathered_* arguments,
+ * mi355cg_dist_scatter_ghosts), or the boundary rows as point-to-point messages (mi355cg_dist_halo).
  * Every rank reduces the gathered partials in rank order, so all ranks take identical decisions.
  * All dist calls are asynchronous on `stream`, a hipStream_t taken literally (NULL = HIP's default
  * stream, which is torch's default stream too), so they order with the caller's collectives.
@@ -144,13 +145,15 @@ int  mi355cg_create_slab(int n, int m, double a, double b, double c, double d, i
                          int y_lo, int y_hi, mi355cg_handle *out);
 int  mi355cg_owned_range(mi355cg_handle h, long long *packed_begin, long long *packed_len, int *y_lo, int *y_hi);
 int  mi355cg_dist_begin(mi355cg_handle h, const mi355cg_params *params, void *stream);
-int  mi355cg_dist_reduce(mi355cg_handle h, int which /*0 stencil, 1 update*/, void *stream);
-int  mi355cg_dist_sums_ptr(mi355cg_handle h, int which, void **dev_ptr, int *count);
-int  mi355cg_dist_stencil(mi355cg_handle h, const double *gathered_update_sums, int nranks,
+int  mi355cg_dist_reduce(mi355cg_handle h, int which /*0 stencil, 1 update*/, int with_rows, void *stream);
+int  mi355cg_dist_sums_ptr(mi355cg_handle h, int which, void **dev_ptr, int *count /*record width*/);
+int  mi355cg_dist_scatter_ghosts(mi355cg_handle h, int vector /*0 r, 1 current direction*/,
+                                 const double *gathered_records, int nranks, int rank, void *stream);
+int  mi355cg_dist_stencil(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride,
                           int rows /*0 all, 1 interior, 2 edge rows*/, void *stream);
 int  mi355cg_dist_flip(mi355cg_handle h);          /* once per stencil phase: new direction becomes current */
-int  mi355cg_dist_update(mi355cg_handle h, const double *gathered_stencil_sums, int nranks, void *stream);
-int  mi355cg_dist_check(mi355cg_handle h, const double *gathered_update_sums, int nranks, void *stream);
+int  mi355cg_dist_update(mi355cg_handle h, const double *gathered_stencil_sums, int nranks, int estride, void *stream);
+int  mi355cg_dist_check(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride, void *stream);
 int  mi355cg_dist_summary(mi355cg_handle h, mi355cg_results *out, int *done);   /* after a stream sync */
 int  mi355cg_dist_history(mi355cg_handle h, int iteration, double *precision, double *residual, double *error);
 int  mi355cg_dist_halo(mi355cg_handle h, int vector /*0 r, 1 current direction*/,

@@ -21,7 +21,7 @@ EXPORTS = [
     "mi355cg_get_solution", "mi355cg_get_recursive_residual", "mi355cg_get_true_residual",
     "mi355cg_set_profiling", "mi355cg_get_kernel_time", "mi355cg_get_layout",
     "mi355cg_slab_rows", "mi355cg_create_slab", "mi355cg_owned_range", "mi355cg_dist_begin",
-    "mi355cg_dist_reduce", "mi355cg_dist_sums_ptr", "mi355cg_dist_stencil", "mi355cg_dist_flip",
+    "mi355cg_dist_reduce", "mi355cg_dist_sums_ptr", "mi355cg_dist_scatter_ghosts", "mi355cg_dist_stencil", "mi355cg_dist_flip",
     "mi355cg_dist_update", "mi355cg_dist_check", "mi355cg_dist_summary", "mi355cg_dist_history",
     "mi355cg_dist_halo", "mi355cg_dist_halo_recv_counts",
 ]
@@ -97,12 +97,13 @@ def load():
     L.mi355cg_create_slab.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int] * 4 + [C.POINTER(H)]
     L.mi355cg_owned_range.argtypes = [H, LLP, LLP, IP, IP]
     L.mi355cg_dist_begin.argtypes = [H, C.POINTER(Params), C.c_void_p]
-    L.mi355cg_dist_reduce.argtypes = [H, C.c_int, C.c_void_p]
+    L.mi355cg_dist_reduce.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_sums_ptr.argtypes = [H, C.c_int, VPP, IP]
-    L.mi355cg_dist_stencil.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mi355cg_dist_scatter_ghosts.argtypes = [H, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mi355cg_dist_stencil.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_flip.argtypes = [H]
-    L.mi355cg_dist_update.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p]
-    L.mi355cg_dist_check.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p]
+    L.mi355cg_dist_update.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mi355cg_dist_check.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_summary.argtypes = [H, C.POINTER(Results), IP]
     DBP = C.POINTER(C.c_double)
     L.mi355cg_dist_history.argtypes = [H, C.c_int, DBP, DBP, DBP]

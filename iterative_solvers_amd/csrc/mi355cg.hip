@@ -41,6 +41,8 @@ int env_int(const char* name, int dflt) {
 
 inline long long round_up(long long v, long long m) { return (v + m - 1) / m * m; }
 
+constexpr int kRecHeader = 8;      // doubles reserved for the sums at the head of a slab record
+
 struct EventPool {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
@@ -73,7 +75,8 @@ struct mi355cg_ctx {
     float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr, *bf = nullptr;
     double* packed = nullptr;           // device scratch, pk_len doubles
     double *partA = nullptr, *partB = nullptr, *partR = nullptr;
-    double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's reduced partials (feed the all-gather)
+    double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's record = reduced partials [+ its two boundary rows] (feeds the all-gather)
+    int rec_width = 0;
     mi355cg_params dist_prm{};                    // slab mode: parameters given to mi355cg_dist_begin
     bool dist_active = false, is_slab = false;
     CgState *sA = nullptr, *sB = nullptr, *summary = nullptr;
@@ -394,8 +397,9 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     if ((rc = alloc_vec(&c->partA, (long long)FA_COUNT * c->strideA))) return cleanup();
     if ((rc = alloc_vec(&c->partB, (long long)FB_COUNT * c->strideB))) return cleanup();
     if ((rc = alloc_vec(&c->partR, 2048))) return cleanup();
-    if ((rc = alloc_vec(&c->sumsA, FA_COUNT))) return cleanup();
-    if ((rc = alloc_vec(&c->sumsB, FB_COUNT))) return cleanup();
+    c->rec_width = kRecHeader + 2 * c->g.Pu;            // [sums | first owned row | last owned row]
+    if ((rc = alloc_vec(&c->sumsA, c->rec_width))) return cleanup();
+    if ((rc = alloc_vec(&c->sumsB, c->rec_width))) return cleanup();
     if (hipMalloc((void**)&c->sA, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->sB, sizeof(CgState)) != hipSuccess ||
         hipMalloc((void**)&c->summary, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->hist, sizeof(HistEntry) * kHist) != hipSuccess ||
         hipHostMalloc((void**)&c->summary_h, sizeof(CgState)) != hipSuccess || hipHostMalloc((void**)&c->hist_h, sizeof(HistEntry) * kHist) != hipSuccess ||
@@ -706,35 +710,65 @@ int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream
 }
 
 // which: 0 = stencil partials (fields FA_*), 1 = update partials (fields FB_*).  Reduces this rank's
-// partials into its sums buffer (device), which the caller all-gathers.
-int mi355cg_dist_reduce(mi355cg_handle c, int which, void* stream) {
+// partials into the head of its record (device).  with_rows != 0 also copies the rank's first and
+// last owned row of the vector the neighbours need next (which 0: the direction the stencil just
+// wrote, call after mi355cg_dist_flip; which 1: the residual) behind the sums, so ONE all-gather
+// carries both the scalars and the halo.
+int mi355cg_dist_reduce(mi355cg_handle c, int which, int with_rows, void* stream) {
     if (!c || !c->dist_active) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run");
     hipStream_t st = pick_stream(c, stream);
+    double* rec = which == 0 ? c->sumsA : c->sumsB;
     if (which == 0)
-        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, c->partA, c->nA_dist, c->strideA, (int)FA_COUNT, 0u, c->sumsA);
+        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, c->partA, c->nA_dist, c->strideA, (int)FA_COUNT, 0u, rec);
     else
         hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, c->partB, c->grid_update, c->strideB, (int)FB_COUNT,
-                           (1u << FB_RMAX) | (1u << FB_DMAX) | (1u << FB_EMAX), c->sumsB);
+                           (1u << FB_RMAX) | (1u << FB_DMAX) | (1u << FB_EMAX), rec);
     HIPCK(hipGetLastError());
+    if (with_rows) {
+        const Geom& g = c->g;
+        const double* v = which == 0 ? c->p[c->cur] : c->r;
+        auto len = [&](int y) -> size_t { return (size_t)(y <= g.half ? g.Pb : g.Pu); };
+        HIPCK(hipMemcpyAsync(rec + kRecHeader, v + (phys_start(g, g.y_lo) - g.base0), sizeof(double) * len(g.y_lo), hipMemcpyDeviceToDevice, st));
+        HIPCK(hipMemcpyAsync(rec + kRecHeader + g.Pu, v + (phys_start(g, g.y_hi) - g.base0), sizeof(double) * len(g.y_hi), hipMemcpyDeviceToDevice, st));
+    }
     return MI355CG_OK;
 }
 int mi355cg_dist_sums_ptr(mi355cg_handle c, int which, void** dev_ptr, int* count) {
     if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
     if (dev_ptr) *dev_ptr = which == 0 ? (void*)c->sumsA : (void*)c->sumsB;
-    if (count) *count = which == 0 ? (int)FA_COUNT : (int)FB_COUNT;
+    if (count) *count = c->rec_width;
+    return MI355CG_OK;
+}
+// After all-gathering full records ([rank][rec_width]): copy the neighbours' boundary rows into this
+// rank's ghost rows of `vector` (0 = r from update records, 1 = current direction from stencil records).
+int mi355cg_dist_scatter_ghosts(mi355cg_handle c, int vector, const double* gathered, int nranks, int rank, void* stream) {
+    if (!c || !gathered) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (rank < 0 || rank >= nranks) return fail(MI355CG_ERR_INVALID, "rank %d outside 0..%d", rank, nranks - 1);
+    hipStream_t st = pick_stream(c, stream);
+    const Geom& g = c->g;
+    double* v = vector == 0 ? c->r : c->p[c->cur];
+    auto len = [&](int y) -> size_t { return (size_t)(y <= g.half ? g.Pb : g.Pu); };
+    const size_t W = (size_t)c->rec_width;
+    if (rank > 0)            // ghost row y_lo-1 = the lower neighbour's LAST owned row
+        HIPCK(hipMemcpyAsync(v + (phys_start(g, g.y_lo - 1) - g.base0), gathered + W * (rank - 1) + kRecHeader + g.Pu,
+                             sizeof(double) * len(g.y_lo - 1), hipMemcpyDeviceToDevice, st));
+    if (rank < nranks - 1)   // ghost row y_hi+1 = the upper neighbour's FIRST owned row
+        HIPCK(hipMemcpyAsync(v + (phys_start(g, g.y_hi + 1) - g.base0), gathered + W * (rank + 1) + kRecHeader,
+                             sizeof(double) * len(g.y_hi + 1), hipMemcpyDeviceToDevice, st));
     return MI355CG_OK;
 }
 
 // rows: 0 = whole slab, 1 = interior rows only, 2 = the first and last owned row (they read the
 // neighbours' ghost rows).  A full stencil phase is either {0} or {1, 2}; call mi355cg_dist_flip once after it.
-int mi355cg_dist_stencil(mi355cg_handle c, const double* gathered_B, int nranks, int rows, void* stream) {
+// `estride` = doubles between consecutive ranks' sums in `gathered_B` (FB_COUNT, or the record width).
+int mi355cg_dist_stencil(mi355cg_handle c, const double* gathered_B, int nranks, int estride, int rows, void* stream) {
     if (!c || !c->dist_active || !gathered_B) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
     const IterCfg cfg = make_cfg(&c->dist_prm);
     StencilWhere w{pick_stream(c, stream), &c->wl, c->grid_stencil, 0};
     if (rows == 1) w = StencilWhere{w.stream, &c->wl_int, c->grid_int, 0};
     else if (rows == 2) w = StencilWhere{w.stream, &c->wl_edge, c->grid_edge, c->grid_int};
     if (rows == 1 && c->wl_int.nitems == 0) return MI355CG_OK;
-    const PartSrc pb{gathered_B, nranks, 1, (int)FB_COUNT};
+    const PartSrc pb{gathered_B, nranks, 1, estride};
     launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, w, pb);
     c->nA_dist = rows == 0 ? c->grid_stencil : c->grid_int + c->grid_edge;
     HIPCK(hipGetLastError());
@@ -745,20 +779,20 @@ int mi355cg_dist_flip(mi355cg_handle c) {
     c->cur ^= 1;
     return MI355CG_OK;
 }
-int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, void* stream) {
+int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, int estride, void* stream) {
     if (!c || !c->dist_active || !gathered_A) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
     const IterCfg cfg = make_cfg(&c->dist_prm);
-    const PartSrc pa{gathered_A, nranks, 1, (int)FA_COUNT};
+    const PartSrc pa{gathered_A, nranks, 1, estride};
     launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, pick_stream(c, stream), pa);
     HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
 // Asynchronous: after the stream reaches this point the summary is in pinned host memory.
-int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, void* stream) {
+int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, int estride, void* stream) {
     if (!c || !c->dist_active || !gathered_B) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
     const IterCfg cfg = make_cfg(&c->dist_prm);
     hipStream_t st = pick_stream(c, stream);
-    launch_check(c, cfg, st, PartSrc{gathered_B, nranks, 1, (int)FB_COUNT});
+    launch_check(c, cfg, st, PartSrc{gathered_B, nranks, 1, estride});
     HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, st));
     HIPCK(hipMemcpyAsync(c->hist_h, c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, st));
     return MI355CG_OK;

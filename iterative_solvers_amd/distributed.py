@@ -2,15 +2,25 @@
 GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI) for the two things that cross ranks.
 
 The reference is single-process (no collectives anywhere); this module is the
-scaling surface around the same kernels.  Per CG iteration and rank:
+scaling surface around the same kernels.  Two ways to move the halo, same kernels:
 
-    stencil (interior rows)      -- overlaps the halo messages still in flight
-    wait halos ; stencil (first + last owned row) ; direction buffers flip
-    all_gather  {(Ap,p), (r,p)}  of every rank        -> alpha on every rank, in rank order
-    isend/irecv boundary rows of the new direction    -- overlaps the update kernel
-    update x, r
-    all_gather  {r.r, max|r|, max|dx|, max|x-u|, ...} -> beta + stop decision on every rank
-    isend/irecv boundary rows of r                    -- overlaps the next interior stencil
+  halo="gather" (default): ONE collective per phase.  Each rank's record = its reduced partial
+    sums followed by its first and last owned row; `all_gather_into_tensor` makes every record
+    visible; each rank copies its neighbours' rows into its ghost rows (two D2D copies) and its
+    consumer kernel reduces the sums in rank order.  2 collectives + 4 kernel launches per
+    iteration from the host: the cheapest to drive from one Python process per GPU.
+
+        stencil (whole slab) ; flip ; record{(Ap,p),(r,p) | new direction rows} ; all_gather
+        update x, r          ;        record{r.r, max-norms | r rows}           ; all_gather
+
+  halo="p2p": the boundary rows travel as isend/irecv pairs with the two neighbours and overlap
+    compute; the sums use a narrow all-gather.
+
+        stencil (interior rows)      -- overlaps the halo messages still in flight
+        wait halos ; stencil (first + last owned row) ; flip
+        all_gather sums ; isend/irecv new direction rows   -- overlaps the update kernel
+        update x, r
+        all_gather sums ; isend/irecv r rows               -- overlaps the next interior stencil
 
 Each rank reduces the gathered per-rank sums in rank order inside the consumer kernel's
 prologue, so all ranks compute bit-identical alpha/beta and take the same stop decision without
@@ -35,6 +45,7 @@ from . import _capi
 from .solver import default_params
 
 FA_COUNT, FB_COUNT = 2, 6          # fields of the stencil / update partial sums (cg_kernels.h)
+REC_HEADER = 8                     # doubles reserved for the sums at the head of a slab record
 
 
 def slab_rows(n: int, world: int, rank: int):
@@ -99,26 +110,31 @@ class SlabEngine:
     def begin(self, params: _capi.Params):
         _capi.check(self._lib.mi355cg_dist_begin(self._h, C.byref(params), self._stream()))
 
-    def reduce(self, which: int):
-        _capi.check(self._lib.mi355cg_dist_reduce(self._h, which, self._stream()))
+    def reduce(self, which: int, with_rows: bool = False):
+        _capi.check(self._lib.mi355cg_dist_reduce(self._h, which, 1 if with_rows else 0, self._stream()))
 
-    def sums(self, which: int) -> torch.Tensor:
+    def record(self, which: int) -> torch.Tensor:
+        """This rank's record: [sums (REC_HEADER doubles) | first owned row | last owned row]."""
         return self._sums[which]
 
-    def stencil(self, gathered_b: torch.Tensor, rows: int = 0):
-        _capi.check(self._lib.mi355cg_dist_stencil(self._h, gathered_b.data_ptr(), gathered_b.numel() // FB_COUNT,
-                                                   rows, self._stream()))
+    def scatter_ghosts(self, vector: int, gathered: torch.Tensor, rank: int):
+        nranks = gathered.numel() // self._sums[0].numel()
+        _capi.check(self._lib.mi355cg_dist_scatter_ghosts(self._h, vector, gathered.data_ptr(), nranks, rank, self._stream()))
+
+    def stencil(self, gathered_b: torch.Tensor, estride: int, rows: int = 0):
+        _capi.check(self._lib.mi355cg_dist_stencil(self._h, gathered_b.data_ptr(), gathered_b.numel() // estride,
+                                                   estride, rows, self._stream()))
 
     def flip(self):
         _capi.check(self._lib.mi355cg_dist_flip(self._h))
 
-    def update(self, gathered_a: torch.Tensor):
-        _capi.check(self._lib.mi355cg_dist_update(self._h, gathered_a.data_ptr(), gathered_a.numel() // FA_COUNT,
-                                                  self._stream()))
+    def update(self, gathered_a: torch.Tensor, estride: int):
+        _capi.check(self._lib.mi355cg_dist_update(self._h, gathered_a.data_ptr(), gathered_a.numel() // estride,
+                                                  estride, self._stream()))
 
-    def check(self, gathered_b: torch.Tensor):
-        _capi.check(self._lib.mi355cg_dist_check(self._h, gathered_b.data_ptr(), gathered_b.numel() // FB_COUNT,
-                                                 self._stream()))
+    def check(self, gathered_b: torch.Tensor, estride: int):
+        _capi.check(self._lib.mi355cg_dist_check(self._h, gathered_b.data_ptr(), gathered_b.numel() // estride,
+                                                 estride, self._stream()))
 
     def summary(self):
         torch.cuda.current_stream().synchronize()
@@ -168,9 +184,11 @@ class _Comm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.stage = self.backend == "gloo"
+        # test hook: run the collectives even at world size 1 (exercises RCCL on a one-GPU box)
+        self.force = os.environ.get("MI355CG_FORCE_COLLECTIVES", "0") == "1" and dist.is_initialized()
 
     def all_gather(self, out: torch.Tensor, local: torch.Tensor):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             out.copy_(local)
             return
         if self.stage and local.is_cuda:
@@ -236,27 +254,39 @@ class DistResults:
 class DistributedCG:
     """CG over row slabs.  `engine` implements the SlabEngine protocol."""
 
-    def __init__(self, engine, group=None, overlap: bool = True):
+    def __init__(self, engine, group=None, halo: str = "gather", overlap: bool = True):
+        assert halo in ("gather", "p2p")
         self.eng = engine
         self.comm = _Comm(group)
-        self.overlap = overlap
-        dev = engine.sums(0).device
-        self.gA = torch.zeros(self.comm.world * FA_COUNT, dtype=torch.float64, device=dev)
-        self.gB = torch.zeros(self.comm.world * FB_COUNT, dtype=torch.float64, device=dev)
+        self.halo = halo
+        self.overlap = overlap and halo == "p2p"
+        rec = engine.record(0)
+        self.W = rec.numel() if halo == "gather" else REC_HEADER       # doubles all-gathered per rank and phase
+        self.gA = torch.zeros(self.comm.world * self.W, dtype=torch.float64, device=rec.device)
+        self.gB = torch.zeros(self.comm.world * self.W, dtype=torch.float64, device=rec.device)
 
     def _gather(self, which: int):
-        self.eng.reduce(which)
-        self.comm.all_gather(self.gA if which == 0 else self.gB, self.eng.sums(which))
+        eng, comm = self.eng, self.comm
+        if self.halo == "gather":
+            eng.reduce(which, with_rows=True)
+            g = self.gA if which == 0 else self.gB
+            comm.all_gather(g, eng.record(which))
+            if comm.world > 1:                              # stencil records carry the direction, update records carry r
+                eng.scatter_ghosts(1 if which == 0 else 0, g, comm.rank)
+        else:
+            eng.reduce(which, with_rows=False)
+            comm.all_gather(self.gA if which == 0 else self.gB, eng.record(which)[:REC_HEADER])
 
     def solve(self, params: _capi.Params, callback=None) -> DistResults:
-        eng, comm = self.eng, self.comm
+        eng, comm, W = self.eng, self.comm, self.W
+        p2p = self.halo == "p2p"
         msg = params.rule == _capi.RULE_MSG_MAXNORM
         t0 = time.perf_counter()
         eng.begin(params)                                   # x = 0, r = b, p = 0 ; partial norms of r0
-        self._gather(1)
-        tok_r = comm.halo_start(eng.halo(0))                # ghost rows of r0 = b
+        self._gather(1)                                     # (gather mode: also the ghost rows of r0 = b)
+        tok_r = comm.halo_start(eng.halo(0)) if p2p else None
         tok_p = None                                        # direction is 0 everywhere: ghosts already right
-        eng.check(self.gB)
+        eng.check(self.gB, W)
         res, done = eng.summary()
         if msg and callback:
             callback(0, res.final_precision, res.final_residual_norm, res.final_error_norm)
@@ -270,19 +300,21 @@ class DistributedCG:
                 m = min(m, every - it_done % every)
             for _ in range(m):
                 if self.overlap and comm.world > 1:
-                    eng.stencil(self.gB, rows=1)            # interior rows: no ghost needed
+                    eng.stencil(self.gB, W, rows=1)         # interior rows: no ghost needed
                     comm.halo_wait(tok_r); comm.halo_wait(tok_p)
-                    eng.stencil(self.gB, rows=2)            # first + last owned row
+                    eng.stencil(self.gB, W, rows=2)         # first + last owned row
                 else:
                     comm.halo_wait(tok_r); comm.halo_wait(tok_p)
-                    eng.stencil(self.gB, rows=0)
+                    eng.stencil(self.gB, W, rows=0)
                 eng.flip()
                 self._gather(0)
-                tok_p = comm.halo_start(eng.halo(1))        # new direction's boundary rows (overlaps the update)
-                eng.update(self.gA)
+                if p2p:
+                    tok_p = comm.halo_start(eng.halo(1))    # new direction's boundary rows (overlaps the update)
+                eng.update(self.gA, W)
                 self._gather(1)
-                tok_r = comm.halo_start(eng.halo(0))        # r's boundary rows (overlaps the next interior stencil)
-            eng.check(self.gB)
+                if p2p:
+                    tok_r = comm.halo_start(eng.halo(0))    # r's boundary rows (overlaps the next interior stencil)
+            eng.check(self.gB, W)
             res, done = eng.summary()
             if msg and callback:
                 for it in range(it_done + 1, res.iterations + 1):
@@ -318,7 +350,8 @@ def bench(args, rule: int) -> dict:
     U = (n // 2 - 1) * (3 * n // 2 - 1)
     y_lo, y_hi = slab_rows(n, world, rank)
     eng = SlabEngine(n, y_lo, y_hi, device=local_rank)
-    cg = DistributedCG(eng, overlap=True)
+    halo = os.environ.get("MI355CG_HALO", "gather")
+    cg = DistributedCG(eng, halo=halo)
 
     def run(iters):
         p = default_params(rule)
@@ -344,7 +377,7 @@ def bench(args, rule: int) -> dict:
                                f"(config-2 size per GPU), matrix-free CG, fixed {args.steps} iterations",
                    "n": n, "unknowns": U, "unknowns_per_gpu": U / world, "rule": args.rule,
                    "value_is": "global CG iterations/s x (unknowns / config-2 unknowns) = config-2-sized slab iterations/s",
-                   "parallelism": f"row-slab x{world}, RCCL all_gather + isend/irecv halos"},
+                   "parallelism": f"row-slab x{world}, RCCL, halo={halo}"},
         "global_iters_per_sec": round(its, 2),
         "hbm_gbps": round(88.0 * U * its / 1e9, 1),
         "hbm_frac_of_8TBps": round(88.0 * U * its / 1e9 / (8000.0 * world), 4),

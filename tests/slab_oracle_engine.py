@@ -20,6 +20,7 @@ from oracle.oracle import OracleGrid
 DBL_MAX = sys.float_info.max
 RULE_MSG, RULE_REL2 = 0, 1
 FA_COUNT, FB_COUNT = 2, 6
+REC_HEADER = 8
 FB_RR, FB_RMAX, FB_DMAX, FB_EMAX, FB_D2, FB_E2 = range(6)
 
 
@@ -37,7 +38,9 @@ class OracleSlabEngine:
         self.packed_begin, self.packed_len = self.own.start, self.own.stop - self.own.start
         self.b = np.zeros(self.U); self.b[self.own] = self.og.rhs()[self.own]
         self.u = np.zeros(self.U); self.u[self.own] = self.og.true_solution()[self.own]
-        self._sums = {0: torch.zeros(FA_COUNT, dtype=torch.float64), 1: torch.zeros(FB_COUNT, dtype=torch.float64)}
+        self.row_w = n - 1                                  # widest row; records pad shorter rows with zeros
+        self.W = REC_HEADER + 2 * self.row_w
+        self._rec = {0: torch.zeros(self.W, dtype=torch.float64), 1: torch.zeros(self.W, dtype=torch.float64)}
 
     # rows 1..n-1 hold unknowns; row_begin(n) = U
     def row_begin(self, y: int) -> int:
@@ -68,17 +71,35 @@ class OracleSlabEngine:
         self.partB = np.array([np.dot(r, r), np.abs(r).max(initial=0.0), np.abs(d).max(initial=0.0),
                                np.abs(e).max(initial=0.0), np.dot(d, d), np.dot(e, e)])
 
-    def reduce(self, which: int):
+    def reduce(self, which: int, with_rows: bool = False):
+        rec = self._rec[which]
         if which == 0:
-            self._sums[0][:] = torch.from_numpy(self.partA.sum(axis=0))
+            rec[:FA_COUNT] = torch.from_numpy(self.partA.sum(axis=0))
         else:
-            self._sums[1][:] = torch.from_numpy(self.partB)
+            rec[:FB_COUNT] = torch.from_numpy(self.partB)
+        if with_rows:
+            v = self.p[self.cur] if which == 0 else self.r
+            for k, y in enumerate((self.y_lo, self.y_hi)):
+                row = v[self.rows(y, y)]
+                seg = rec[REC_HEADER + k * self.row_w: REC_HEADER + (k + 1) * self.row_w]
+                seg.zero_()
+                seg[:row.size] = torch.from_numpy(row)
 
-    def sums(self, which: int) -> torch.Tensor:
-        return self._sums[which]
+    def record(self, which: int) -> torch.Tensor:
+        return self._rec[which]
 
-    def _decide(self, gathered_b: torch.Tensor):
-        g = gathered_b.numpy().reshape(-1, FB_COUNT)
+    def scatter_ghosts(self, vector: int, gathered: torch.Tensor, rank: int):
+        g = gathered.numpy().reshape(-1, self.W)
+        v = self.r if vector == 0 else self.p[self.cur]
+        if rank > 0 and self.y_lo - 1 >= 1:
+            sl = self.rows(self.y_lo - 1, self.y_lo - 1)
+            v[sl] = g[rank - 1, REC_HEADER + self.row_w: REC_HEADER + self.row_w + (sl.stop - sl.start)]
+        if rank < g.shape[0] - 1 and self.y_hi + 1 <= self.n - 1:
+            sl = self.rows(self.y_hi + 1, self.y_hi + 1)
+            v[sl] = g[rank + 1, REC_HEADER: REC_HEADER + (sl.stop - sl.start)]
+
+    def _decide(self, gathered_b: torch.Tensor, estride: int):
+        g = gathered_b.numpy().reshape(-1, estride)
         rr = 0.0
         for k in range(g.shape[0]):                      # rank order
             rr += g[k, FB_RR]
@@ -108,10 +129,10 @@ class OracleSlabEngine:
         self.hist[s["it"]] = (dmax, rmax, emax)
         return out
 
-    def stencil(self, gathered_b: torch.Tensor, rows: int = 0):
+    def stencil(self, gathered_b: torch.Tensor, estride: int, rows: int = 0):
         if self.state["done"]:
             return
-        d = self._decide(gathered_b)
+        d = self._decide(gathered_b, estride)
         self._pending = d
         if d["done"]:
             if rows in (0, 2):
@@ -144,11 +165,11 @@ class OracleSlabEngine:
     def flip(self):
         self.cur ^= 1
 
-    def update(self, gathered_a: torch.Tensor):
+    def update(self, gathered_a: torch.Tensor, estride: int):
         s = self.state
         if s["done"]:
             return
-        g = gathered_a.numpy().reshape(-1, FA_COUNT)
+        g = gathered_a.numpy().reshape(-1, estride)
         pap = rz = 0.0
         for k in range(g.shape[0]):
             pap += g[k, 0]; rz += g[k, 1]
@@ -160,8 +181,8 @@ class OracleSlabEngine:
         self._update_partials(self.x[o], x0)
         s.update(it=s["it"] + 1, first=0, rz=rz)
 
-    def check(self, gathered_b: torch.Tensor):
-        self._summary = dict(self.state) if self.state["done"] else self._decide(gathered_b)
+    def check(self, gathered_b: torch.Tensor, estride: int):
+        self._summary = dict(self.state) if self.state["done"] else self._decide(gathered_b, estride)
 
     def summary(self):
         s = self._summary

@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, rule, overlap, outdir, eps_kw):
+def _worker(rank, world, port, n, rule, halo, outdir, eps_kw):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -28,7 +28,7 @@ def _worker(rank, world, port, n, rule, overlap, outdir, eps_kw):
         from slab_oracle_engine import OracleSlabEngine
         y_lo, y_hi = slab_rows(n, world, rank)
         eng = OracleSlabEngine(n, y_lo, y_hi)
-        cg = DistributedCG(eng, overlap=overlap)
+        cg = DistributedCG(eng, halo=halo)
         p = default_params(rule)
         for k, v in eps_kw.items():
             setattr(p, k, v)
@@ -41,10 +41,10 @@ def _worker(rank, world, port, n, rule, overlap, outdir, eps_kw):
         dist.destroy_process_group()
 
 
-def _run(world, n, rule, overlap, **eps_kw):
+def _run(world, n, rule, halo, **eps_kw):
     port = 29000 + (os.getpid() * 7 + world * 131 + n) % 2000
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, n, rule, overlap, d, eps_kw), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, n, rule, halo, d, eps_kw), nprocs=world, join=True)
         parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
         parts = [{k: p[k] for k in p.files} for p in parts]
     x = np.concatenate([p["x"] for p in parts])
@@ -55,22 +55,23 @@ def _run(world, n, rule, overlap, **eps_kw):
     return x, parts[0]
 
 
-@pytest.mark.parametrize("world,overlap", [(2, True), (2, False), (3, True)])
-def test_rel2norm_two_and_three_ranks_match_the_oracle(world, overlap):
+@pytest.mark.parametrize("world,halo", [(2, "gather"), (2, "p2p"), (3, "gather"), (3, "p2p")])
+def test_rel2norm_two_and_three_ranks_match_the_oracle(world, halo):
     from oracle.oracle import OracleGrid
     n = 32
     ref = OracleGrid(n, n).mf_solve(eps=1e-8, max_iterations=10 ** 5)
-    x, r0 = _run(world, n, 1, overlap, eps_rel=1e-8, max_iterations=10 ** 5)
+    x, r0 = _run(world, n, 1, halo, eps_rel=1e-8, max_iterations=10 ** 5)
     assert int(r0["it"]) == ref.iterations and bool(r0["conv"])
     assert np.abs(x - ref.x).max() <= 1e-10 * np.abs(ref.x).max()
     assert abs(float(r0["rnorm2"]) - ref.r_norm) / ref.initial_r_norm <= 1e-12
 
 
-def test_msg_rule_callbacks_and_stop_reason_two_ranks():
+@pytest.mark.parametrize("halo", ["gather", "p2p"])
+def test_msg_rule_callbacks_and_stop_reason_two_ranks(halo):
     from oracle.oracle import OracleGrid
     n = 24
     ref = OracleGrid(n, n).msg_solve(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
-    x, r0 = _run(2, n, 0, True, eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, callback_every=10)
+    x, r0 = _run(2, n, 0, halo, eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, callback_every=10)
     assert (int(r0["it"]), int(r0["reason"])) == (ref.iterations, ref.stop_reason)
     its = [int(c[0]) for c in r0["cbs"]]
     want = [0, 1] + [i for i in range(10, ref.iterations + 1, 10) if i != ref.iterations or False] + [ref.iterations]

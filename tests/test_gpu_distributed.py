@@ -22,8 +22,8 @@ def _params(isa, rule, **kw):
 
 
 @pytest.mark.parametrize("rule", [0, 1])
-@pytest.mark.parametrize("overlap", [False, True])
-def test_world1_matches_native_solve(rule, overlap):
+@pytest.mark.parametrize("halo", ["gather", "p2p"])
+def test_world1_matches_native_solve(rule, halo):
     import torch
     import iterative_solvers_amd as isa
     from iterative_solvers_amd.distributed import DistributedCG, SlabEngine
@@ -34,7 +34,7 @@ def test_world1_matches_native_solve(rule, overlap):
     x_n = native._handle.solution()
     eng = SlabEngine(N, 1, N - 1, device=0)
     cbs = []
-    res_d = DistributedCG(eng, overlap=overlap).solve(_params(isa, rule, **kw), callback=lambda *a: cbs.append(a))
+    res_d = DistributedCG(eng, halo=halo).solve(_params(isa, rule, **kw), callback=lambda *a: cbs.append(a))
     assert (res_d.iterations, res_d.stop_reason, res_d.converged) == (res_n.iterations, res_n.stop_reason, bool(res_n.converged))
     assert np.array_equal(eng.solution(), x_n)                   # same kernels, same reduction tree
     assert res_d.r_norm2 == res_n.r_norm2 and res_d.final_residual_norm == res_n.final_residual_norm
@@ -42,7 +42,7 @@ def test_world1_matches_native_solve(rule, overlap):
         assert cbs[0][0] == 0 and cbs[1][0] == 1 and cbs[-1][0] == res_d.iterations
 
 
-def _worker(rank, world, port, n, rule, overlap, outdir, kw):
+def _worker(rank, world, port, n, rule, halo, outdir, kw):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch
@@ -58,7 +58,7 @@ def _worker(rank, world, port, n, rule, overlap, outdir, kw):
         for k, v in kw.items():
             setattr(p, k, v)
         cbs = []
-        res = DistributedCG(eng, overlap=overlap).solve(p, callback=lambda *a: cbs.append(a))
+        res = DistributedCG(eng, halo=halo).solve(p, callback=lambda *a: cbs.append(a))
         np.savez(os.path.join(outdir, f"r{rank}.npz"), x=eng.solution(), r=eng.recursive_residual(), begin=eng.packed_begin,
                  it=res.iterations, reason=res.stop_reason, rnorm2=res.r_norm2, rmax=res.final_residual_norm,
                  cbs=np.array(cbs, dtype=float).reshape(-1, 4))
@@ -66,11 +66,11 @@ def _worker(rank, world, port, n, rule, overlap, outdir, kw):
         dist.destroy_process_group()
 
 
-def _run(world, n, rule, overlap, **kw):
+def _run(world, n, rule, halo, **kw):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() * 13 + world * 17 + n) % 1500
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, n, rule, overlap, d, kw), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, n, rule, halo, d, kw), nprocs=world, join=True)
         parts = []
         for r in range(world):
             with np.load(os.path.join(d, f"r{r}.npz")) as f:
@@ -81,12 +81,12 @@ def _run(world, n, rule, overlap, **kw):
     return np.concatenate([p["x"] for p in parts]), np.concatenate([p["r"] for p in parts]), parts[0]
 
 
-@pytest.mark.parametrize("world,n,overlap", [(2, 64, True), (3, 64, True), (2, 64, False), (3, 130, True)])
-def test_slabs_over_gloo_match_the_oracle_rel2(world, n, overlap):
+@pytest.mark.parametrize("world,n,halo", [(2, 64, "gather"), (3, 64, "p2p"), (2, 64, "p2p"), (3, 130, "gather"), (4, 258, "gather")])
+def test_slabs_over_gloo_match_the_oracle_rel2(world, n, halo):
     from oracle.oracle import OracleGrid
     og = OracleGrid(n, n)
     ref = og.mf_solve(eps=1e-8, max_iterations=10 ** 5)
-    x, r, r0 = _run(world, n, 1, overlap, eps_rel=1e-8, max_iterations=10 ** 5)
+    x, r, r0 = _run(world, n, 1, halo, eps_rel=1e-8, max_iterations=10 ** 5)
     assert int(r0["it"]) == ref.iterations
     assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
     assert abs(float(r0["rnorm2"]) - ref.r_norm) / ref.initial_r_norm <= 1e-12
@@ -94,13 +94,31 @@ def test_slabs_over_gloo_match_the_oracle_rel2(world, n, overlap):
     assert np.abs(r - (og.rhs() - og.apply(x))).max() <= 1e-9 * np.abs(og.rhs()).max()
 
 
-def test_slabs_over_gloo_msg_rule():
+@pytest.mark.parametrize("halo", ["gather", "p2p"])
+def test_slabs_over_gloo_msg_rule(halo):
     from oracle.oracle import OracleGrid
     n = 64
     og = OracleGrid(n, n)
     ref = og.msg_solve(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
-    x, r, r0 = _run(2, n, 0, True, eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
+    x, r, r0 = _run(2, n, 0, halo, eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
     assert (int(r0["it"]), int(r0["reason"])) == (ref.iterations, ref.stop_reason)
     assert [int(c[0]) for c in r0["cbs"]] == [c[0] for c in ref.callbacks]
     assert np.abs(np.array(r0["cbs"])[:, 2] - np.array(ref.callbacks)[:, 2]).max() / ref.initial_r_norm2 <= 1e-12
     assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+
+
+def test_bench_distributed_leg_runs_under_torchrun_with_rccl():
+    """bench.py's N > 1 code path (RCCL process group, device-side all_gather of library-owned
+    records) launched the way the harness launches it, on the one GPU of this box."""
+    import json
+    import subprocess
+    env = dict(os.environ, MI355CG_BENCH_DIST="1", MI355CG_FORCE_COLLECTIVES="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29871", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "60", "--warmup", "10", "--n", "512"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["steps"] == 60 and j["value"] > 0 and j["scaling"] == "weak"
+    assert "halo=gather" in j["config"]["parallelism"]
