@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--n", type=int, default=4096, help="grid intervals per side on one GPU")
+    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid intervals per side on one GPU")
     ap.add_argument("--rule", choices=["rel2", "msg"], default="rel2")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")

@@ -115,7 +115,7 @@ def test_bench_distributed_leg_runs_under_torchrun_with_rccl():
     env = dict(os.environ, MI355CG_BENCH_DIST="1", MI355CG_FORCE_COLLECTIVES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29871", os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--steps", "60", "--warmup", "10", "--n", "512"]
+           "--gpus", "1", "--steps", "60", "--warmup", "10", "--grid", "512"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
