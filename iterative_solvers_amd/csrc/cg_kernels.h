@@ -561,6 +561,35 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts(const double* part, int
     }
 }
 
+// Slab record = [sums (block 0 reduces the partials) | first owned row | last owned row] in ONE launch.
+struct RecordArgs {
+    const double* part; int n, stride, nf; unsigned max_mask;
+    double* rec; int header, row_slot;                 // rows land at rec + header and rec + header + row_slot
+    const double* v; long long off_lo, off_hi; int len_lo, len_hi;   // v == nullptr: sums only
+};
+__global__ __launch_bounds__(kBlock) void k_make_record(const RecordArgs a) {
+    __shared__ double lds[kWaves];
+    if (blockIdx.x == 0) {
+        for (int f = 0; f < a.nf; ++f) {
+            const double t = ((a.max_mask >> f) & 1u) ? reduce_parts<true>(a.part + f * a.stride, a.n, 1, lds)
+                                                      : reduce_parts<false>(a.part + f * a.stride, a.n, 1, lds);
+            if (threadIdx.x == 0) a.rec[f] = t;
+        }
+        return;
+    }
+    if (!a.v) return;
+    const int nb = gridDim.x - 1, b = blockIdx.x - 1;
+    for (int i = b * kBlock + threadIdx.x; i < a.len_lo; i += nb * kBlock) a.rec[a.header + i] = a.v[a.off_lo + i];
+    for (int i = b * kBlock + threadIdx.x; i < a.len_hi; i += nb * kBlock) a.rec[a.header + a.row_slot + i] = a.v[a.off_hi + i];
+}
+// Neighbours' boundary rows out of the all-gathered records into this rank's two ghost rows.
+struct ScatterArgs { const double* src_lo; const double* src_hi; double* dst_lo; double* dst_hi; int len_lo, len_hi; };
+__global__ __launch_bounds__(kBlock) void k_scatter_ghosts(const ScatterArgs a) {
+    const int stride = gridDim.x * kBlock;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.len_lo; i += stride) a.dst_lo[i] = a.src_lo[i];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.len_hi; i += stride) a.dst_hi[i] = a.src_hi[i];
+}
+
 // ---- packed (reference order) <-> storage layout ---------------------------------------------------
 // Packed index i (relative to the first owned row) of the reference's unknown vector
 // (grid_system.cpp:84-111) <-> node (x, y) <-> storage offset.

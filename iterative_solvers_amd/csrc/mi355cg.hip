@@ -717,20 +717,19 @@ int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream
 int mi355cg_dist_reduce(mi355cg_handle c, int which, int with_rows, void* stream) {
     if (!c || !c->dist_active) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run");
     hipStream_t st = pick_stream(c, stream);
-    double* rec = which == 0 ? c->sumsA : c->sumsB;
-    if (which == 0)
-        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, c->partA, c->nA_dist, c->strideA, (int)FA_COUNT, 0u, rec);
-    else
-        hipLaunchKernelGGL(k_reduce_parts, dim3(1), dim3(kBlock), 0, st, c->partB, c->grid_update, c->strideB, (int)FB_COUNT,
-                           (1u << FB_RMAX) | (1u << FB_DMAX) | (1u << FB_EMAX), rec);
-    HIPCK(hipGetLastError());
+    const Geom& g = c->g;
+    RecordArgs a{};
+    a.rec = which == 0 ? c->sumsA : c->sumsB; a.header = kRecHeader; a.row_slot = g.Pu;
+    if (which == 0) { a.part = c->partA; a.n = c->nA_dist; a.stride = c->strideA; a.nf = FA_COUNT; a.max_mask = 0u; }
+    else { a.part = c->partB; a.n = c->grid_update; a.stride = c->strideB; a.nf = FB_COUNT;
+           a.max_mask = (1u << FB_RMAX) | (1u << FB_DMAX) | (1u << FB_EMAX); }
     if (with_rows) {
-        const Geom& g = c->g;
-        const double* v = which == 0 ? c->p[c->cur] : c->r;
-        auto len = [&](int y) -> size_t { return (size_t)(y <= g.half ? g.Pb : g.Pu); };
-        HIPCK(hipMemcpyAsync(rec + kRecHeader, v + (phys_start(g, g.y_lo) - g.base0), sizeof(double) * len(g.y_lo), hipMemcpyDeviceToDevice, st));
-        HIPCK(hipMemcpyAsync(rec + kRecHeader + g.Pu, v + (phys_start(g, g.y_hi) - g.base0), sizeof(double) * len(g.y_hi), hipMemcpyDeviceToDevice, st));
+        a.v = which == 0 ? c->p[c->cur] : c->r;
+        a.off_lo = phys_start(g, g.y_lo) - g.base0; a.len_lo = g.y_lo <= g.half ? g.Pb : g.Pu;
+        a.off_hi = phys_start(g, g.y_hi) - g.base0; a.len_hi = g.y_hi <= g.half ? g.Pb : g.Pu;
     }
+    hipLaunchKernelGGL(k_make_record, dim3(with_rows ? 1 + 32 : 1), dim3(kBlock), 0, st, a);
+    HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
 int mi355cg_dist_sums_ptr(mi355cg_handle c, int which, void** dev_ptr, int* count) {
@@ -747,14 +746,20 @@ int mi355cg_dist_scatter_ghosts(mi355cg_handle c, int vector, const double* gath
     hipStream_t st = pick_stream(c, stream);
     const Geom& g = c->g;
     double* v = vector == 0 ? c->r : c->p[c->cur];
-    auto len = [&](int y) -> size_t { return (size_t)(y <= g.half ? g.Pb : g.Pu); };
     const size_t W = (size_t)c->rec_width;
-    if (rank > 0)            // ghost row y_lo-1 = the lower neighbour's LAST owned row
-        HIPCK(hipMemcpyAsync(v + (phys_start(g, g.y_lo - 1) - g.base0), gathered + W * (rank - 1) + kRecHeader + g.Pu,
-                             sizeof(double) * len(g.y_lo - 1), hipMemcpyDeviceToDevice, st));
-    if (rank < nranks - 1)   // ghost row y_hi+1 = the upper neighbour's FIRST owned row
-        HIPCK(hipMemcpyAsync(v + (phys_start(g, g.y_hi + 1) - g.base0), gathered + W * (rank + 1) + kRecHeader,
-                             sizeof(double) * len(g.y_hi + 1), hipMemcpyDeviceToDevice, st));
+    ScatterArgs a{};
+    if (rank > 0) {            // ghost row y_lo-1 = the lower neighbour's LAST owned row
+        a.src_lo = gathered + W * (rank - 1) + kRecHeader + g.Pu;
+        a.dst_lo = v + (phys_start(g, g.y_lo - 1) - g.base0);
+        a.len_lo = (g.y_lo - 1) <= g.half ? g.Pb : g.Pu;
+    }
+    if (rank < nranks - 1) {   // ghost row y_hi+1 = the upper neighbour's FIRST owned row
+        a.src_hi = gathered + W * (rank + 1) + kRecHeader;
+        a.dst_hi = v + (phys_start(g, g.y_hi + 1) - g.base0);
+        a.len_hi = (g.y_hi + 1) <= g.half ? g.Pb : g.Pu;
+    }
+    if (a.len_lo || a.len_hi) hipLaunchKernelGGL(k_scatter_ghosts, dim3(32), dim3(kBlock), 0, st, a);
+    HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
 
