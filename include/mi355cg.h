@@ -75,6 +75,7 @@ typedef struct mi355cg_params {
     int    diagnostics;        /* REL_2NORM: reproduce the per-iteration diagnostics + callback  */
     int    sync_every;         /* iterations enqueued between host polls; 0 = automatic          */
     int    fixed_iterations;   /* bench mode: ignore every convergence test, run max_iterations  */
+    double inner_eps;          /* F32_MIXED: relative tolerance of each fp32 inner solve (0 = 1e-4) */
 } mi355cg_params;
 
 typedef struct mi355cg_results {

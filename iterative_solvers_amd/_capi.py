@@ -32,7 +32,8 @@ class Params(C.Structure):
                 ("eps_precision", C.c_double), ("eps_residual", C.c_double),
                 ("eps_exact_error", C.c_double), ("eps_rel", C.c_double),
                 ("use_true_solution", C.c_int), ("callback_every", C.c_int),
-                ("diagnostics", C.c_int), ("sync_every", C.c_int), ("fixed_iterations", C.c_int)]
+                ("diagnostics", C.c_int), ("sync_every", C.c_int), ("fixed_iterations", C.c_int),
+                ("inner_eps", C.c_double)]
 
 
 class Results(C.Structure):

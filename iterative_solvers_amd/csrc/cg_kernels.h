@@ -561,6 +561,28 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts(const double* part, int
     }
 }
 
+// ---- mixed precision (fp32 inner CG inside fp64 iterative refinement; no reference twin) ------------
+// rf = (float)(b - ax) over the whole stored range (pads/ghosts stay 0) and partial sums of (b - ax)^2
+// over the owned range: forms the fp64 true residual, its norm and the fp32 right-hand side in one pass.
+__global__ __launch_bounds__(kBlock) void k_residual_to_f32(long long total, long long own_begin, long long own_len,
+                                                           const double* b, const double* ax, float* rf, double* part) {
+    __shared__ double lds[kWaves];
+    const long long stride = (long long)gridDim.x * kBlock;
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const double d = b[i] - ax[i];
+        rf[i] = (float)d;
+        if (i >= own_begin && i < own_begin + own_len) s += d * d;
+    }
+    const double t = block_reduce<false>(s, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+// x64 += (double) d32 over the owned range
+__global__ __launch_bounds__(kBlock) void k_accumulate_f32(long long begin, long long len, double* x, const float* d) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride) x[i] += (double)d[i];
+}
+
 // Slab record = [sums (block 0 reduces the partials) | first owned row | last owned row] in ONE launch.
 struct RecordArgs {
     const double* part; int n, stride, nf; unsigned max_mask;

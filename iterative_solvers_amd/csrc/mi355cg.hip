@@ -69,6 +69,7 @@ struct mi355cg_ctx {
     int grid_stencil = 0, grid_update = 0, rows_per_item = 0, depth = 4;
     int update_mode = 1, stencil_desc = 1, update_desc = 0, update_unroll = 4;   // launch-shape knobs (env)
     int strideA = 0, strideB = 0;
+    struct Plan { WorkList wl; int grid_stencil = 0, grid_update = 0, rows_per_item = 0; } plan32;   // fp32 kernels (VEC = 4)
 
     // device vectors in storage layout (fp64 set always; fp32 set for F32_MIXED)
     double *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
@@ -357,6 +358,122 @@ void prof_collect(mi355cg_ctx* c) {
 
 }  // namespace
 
+// ---- F32_MIXED: fp32 inner CG inside fp64 iterative refinement ------------------------------------
+// No reference twin (the reference is fp64 only): the pin is the fp64 TRUE residual of the returned x,
+// computed with the bit-exact fp64 operator.  Outer step: d = CG_fp32(A, (float) r) ; x += d ;
+// r = b - A x in fp64.  Only the relative 2-norm rule is offered.
+namespace {
+
+struct PlanSwap {       // run the launch helpers on the fp32 launch geometry for the lifetime of the guard
+    mi355cg_ctx* c; WorkList wl; int gs, gu;
+    explicit PlanSwap(mi355cg_ctx* c_) : c(c_), wl(c_->wl), gs(c_->grid_stencil), gu(c_->grid_update) {
+        c->wl = c->plan32.wl; c->grid_stencil = c->plan32.grid_stencil; c->grid_update = c->plan32.grid_update;
+    }
+    ~PlanSwap() { c->wl = wl; c->grid_stencil = gs; c->grid_update = gu; }
+};
+
+int poll_summary(mi355cg_ctx* c, const IterCfg& cfg) {
+    launch_check(c, cfg, c->stream, own_partB(c));
+    HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return MI355CG_OK;
+}
+
+// fp32 CG on (xf, rf): xf = 0 on entry, rf holds the right-hand side and ends as the recursive residual.
+int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volatile int* stop_flag, int* its, bool* interrupted) {
+    PlanSwap guard(c);
+    const size_t bytes = sizeof(float) * c->storage_len;
+    HIPCK(hipMemsetAsync(c->xf, 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->pf[0], 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->pf[1], 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->apf, 0, bytes, c->stream));
+    c->cur = 0;
+    launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[0], c->apf, (const float*)nullptr, true, c->stream, own_partA(c));
+    HIPCK(hipGetLastError());
+    if (int rc = poll_summary(c, cfg)) return rc;
+    int done_its = 0;
+    while (!c->summary_h->done) {
+        if (stop_flag && *stop_flag) { *interrupted = true; break; }
+        const int m = std::max(1, std::min(sync_every, cfg.rp.max_iterations - done_its));
+        for (int k = 0; k < m; ++k) {
+            hipEvent_t e0 = nullptr;
+            prof_begin(c, 0, &e0);
+            launch_iteration_stencil<float, 4>(c, cfg, c->rf, c->pf, c->apf, whole_slab(c), own_partB(c));
+            c->cur ^= 1;
+            prof_end(c, 0, e0);
+            prof_begin(c, 1, &e0);
+            launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[c->cur], c->apf, (const float*)nullptr, false, c->stream, own_partA(c));
+            prof_end(c, 1, e0);
+        }
+        HIPCK(hipGetLastError());
+        if (int rc = poll_summary(c, cfg)) return rc;
+        done_its = c->summary_h->it;
+    }
+    *its = c->summary_h->it;
+    return MI355CG_OK;
+}
+
+int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
+                const volatile int* stop_flag, mi355cg_results* out) {
+    if (prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "F32_MIXED offers the REL_2NORM rule only");
+    if (c->is_slab) return fail(MI355CG_ERR_INVALID, "F32_MIXED is single-GPU only");
+    const auto t0 = std::chrono::steady_clock::now();
+    c->events.reset(); c->ev_pairs[0].clear(); c->ev_pairs[1].clear();
+    const double inner_eps = prm->inner_eps > 0 ? prm->inner_eps : 1e-4;
+    const int sync_every = std::min(prm->sync_every > 0 ? prm->sync_every : 200, kHist);
+    const int rgrid = 1024;
+    auto residual_pass = [&](double* norm) -> int {      // rf = (float)(b - ap64), *norm = ||b - ap64||_2
+        hipLaunchKernelGGL(k_residual_to_f32, dim3(rgrid), dim3(kBlock), 0, c->stream, c->storage_len, c->g.own_begin, c->g.own_len,
+                           c->b, c->ap, c->rf, c->partR);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * rgrid, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        double s = 0; for (int i = 0; i < rgrid; ++i) s += c->partR_h[i];
+        *norm = std::sqrt(s);
+        return MI355CG_OK;
+    };
+    const size_t bytes64 = sizeof(double) * c->storage_len;
+    HIPCK(hipMemsetAsync(c->x, 0, bytes64, c->stream));
+    HIPCK(hipMemsetAsync(c->ap, 0, bytes64, c->stream));
+    double bnorm = 0, rnorm = 0;
+    if (int rc = residual_pass(&bnorm)) return rc;       // x = 0: r = b
+    rnorm = bnorm;
+    int total = 0, outer = 0;
+    bool interrupted = false, converged = bnorm == 0.0;
+    while (!converged && total < prm->max_iterations && !interrupted) {
+        mi355cg_params ip = *prm;
+        ip.eps_rel = inner_eps; ip.max_iterations = prm->max_iterations - total; ip.diagnostics = 0;
+        const IterCfg cfg = make_cfg(&ip);
+        int its = 0;
+        if (int rc = inner_cg_f32(c, cfg, sync_every, stop_flag, &its, &interrupted)) return rc;
+        total += its; ++outer;
+        hipLaunchKernelGGL(k_accumulate_f32, dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->x, c->xf);
+        launch_apply<double, 2>(c, c->x, c->ap);
+        const double prev = rnorm;
+        if (int rc = residual_pass(&rnorm)) return rc;
+        if (cb) cb(user, total, 0.0, rnorm, 0.0);
+        converged = !prm->fixed_iterations && rnorm <= prm->eps_rel * bnorm;
+        if (prm->fixed_iterations || its == 0) break;
+        if (!converged && rnorm > 0.5 * prev) break;      // fp32 cannot improve this x any further
+    }
+    // leave the fp64 residual of the returned x in c->r for mi355cg_get_recursive_residual
+    hipLaunchKernelGGL((k_sub<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->ap, c->r);
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->solved = true; c->cur = 0;
+    prof_collect(c);
+    mi355cg_results res{};
+    res.iterations = total; res.converged = converged ? 1 : 0;
+    res.stop_reason = interrupted ? MI355CG_STOP_INTERRUPTED : (converged ? MI355CG_STOP_RESIDUAL : MI355CG_STOP_ITERATIONS);
+    res.final_residual_norm = res.final_precision = res.final_error_norm = DBL_MAX;
+    res.r_norm2 = rnorm; res.initial_r_norm2 = bnorm;
+    res.refine_outer = outer; res.refine_true_rel = bnorm > 0 ? rnorm / bnorm : 0.0;
+    res.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (out) *out = res;
+    return MI355CG_OK;
+}
+
+}  // namespace
+
 // ====================================================================================================
 extern "C" {
 
@@ -384,8 +501,14 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     c->device = device; c->dtype = dtype; c->gp = gp; c->is_slab = slab;
     const int vec = 2;                      // fp64 layout; the fp32 kernels use VEC=4 on the same pitches
     build_geom(c, vec, y_lo, y_hi);
+    if (dtype == MI355CG_F32_MIXED) {       // the fp32 kernels use 256-column strips (float4 per lane) on the same pitches
+        build_worklist(c, 4);
+        c->plan32.wl = c->wl; c->plan32.grid_stencil = c->grid_stencil; c->plan32.grid_update = c->grid_update;
+        c->plan32.rows_per_item = c->rows_per_item;
+    }
     build_worklist(c, vec);
-    c->strideA = std::max(c->grid_stencil, c->grid_int + c->grid_edge); c->strideB = c->grid_update;
+    c->strideA = std::max({c->grid_stencil, c->grid_int + c->grid_edge, c->plan32.grid_stencil});
+    c->strideB = std::max(c->grid_update, c->plan32.grid_update);
 
     int rc = MI355CG_OK;
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
@@ -393,6 +516,14 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     const long long L = c->storage_len;
     double** vecs[] = {&c->x, &c->r, &c->p[0], &c->p[1], &c->ap, &c->b, &c->u};
     for (auto v : vecs) if ((rc = alloc_vec(v, L))) return cleanup();
+    if (dtype == MI355CG_F32_MIXED) {
+        float** fv[] = {&c->xf, &c->rf, &c->pf[0], &c->pf[1], &c->apf};
+        for (auto v : fv) {
+            if (hipMalloc((void**)v, sizeof(float) * L) != hipSuccess || hipMemset(*v, 0, sizeof(float) * L) != hipSuccess) {
+                rc = fail(MI355CG_ERR_HIP, "fp32 vector allocation failed"); return cleanup();
+            }
+        }
+    }
     if ((rc = alloc_vec(&c->packed, std::max<long long>(c->pk_len, 1)))) return cleanup();
     if ((rc = alloc_vec(&c->partA, (long long)FA_COUNT * c->strideA))) return cleanup();
     if ((rc = alloc_vec(&c->partB, (long long)FB_COUNT * c->strideB))) return cleanup();
@@ -497,14 +628,15 @@ void mi355cg_default_params(mi355cg_params* p, int rule) {
     p->diagnostics = 0;
     p->sync_every = 0;
     p->fixed_iterations = 0;
+    p->inner_eps = 0.0;
 }
 
 int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
                   const volatile int* stop_flag, mi355cg_results* out) {
     if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
     if (prm->rule != MI355CG_RULE_MSG_MAXNORM && prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "unknown rule %d", prm->rule);
-    if (c->dtype != MI355CG_F64) return fail(MI355CG_ERR_INVALID, "F32_MIXED solve is not wired in this build yet");
     HIPCK(hipSetDevice(c->device));
+    if (c->dtype == MI355CG_F32_MIXED) return solve_mixed(c, prm, cb, user, stop_flag, out);
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
     const IterCfg cfg = make_cfg(prm);
     const bool diag = cfg.want_diag != 0;

@@ -100,7 +100,10 @@ class _Handle:
         res = _capi.Results()
         cb = _capi.ITER_CB(lambda user, it, p, r, e: callback(it, p, r, e)) if callback else _capi.ITER_CB()
         sp = C.cast(C.pointer(stop_flag), C.c_void_p) if stop_flag is not None else None
-        _capi.check(self._lib.mi355cg_solve(self._h, C.byref(params), cb, None, sp, C.byref(res)))
+        rc = self._lib.mi355cg_solve(self._h, C.byref(params), cb, None, sp, C.byref(res))
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(self._lib.mi355cg_last_error().decode())     # std::invalid_argument
+        _capi.check(rc)
         return res
 
     def set_profiling(self, on: bool):
@@ -180,7 +183,9 @@ class MatrixFreeSolver:
     def getIterations(self): return self.iterations
     def getName(self): return self.name
 
-    def solve(self, true_solution=None, fixed_iterations: bool = False, sync_every: int = 0) -> np.ndarray:
+    def solve(self, true_solution=None, fixed_iterations: bool = False, sync_every: int = 0,
+              inner_eps: float = 0.0) -> np.ndarray:
+        """inner_eps only matters for a MatrixFreeSystem created with dtype=F32_MIXED (config 3)."""
         h = self.system._handle
         h.set_rhs(self.b)
         p = default_params(_capi.RULE_REL_2NORM)
@@ -188,6 +193,7 @@ class MatrixFreeSolver:
         p.diagnostics = 1 if self.iteration_callback else 0
         p.fixed_iterations = 1 if fixed_iterations else 0
         p.sync_every = sync_every
+        p.inner_eps = inner_eps
         res = h.solve(p, self.iteration_callback)
         self.iterations, self.last_results = res.iterations, res
         if self.completion_callback:                              # matrix_free_system.cpp:472-479
@@ -297,7 +303,7 @@ class DirichletSolver:
     def enableMaxIterationsStopping(self, on): self.use_max_iterations = on      # never read (as in the reference)
     def setIterationCallback(self, cb): self.iteration_callback = cb
     def setCompletionCallback(self, cb): self.completion_callback = cb
-    def getMethodName(self): return "Метод серединных градиентов"
+    def getMethodName(self): return self.solver.getName() if self.solver is not None else "МСГ"    # dirichlet_solver.hpp:159-161
     def getGridSystem(self): return self.grid
     def getSolution(self): return self.solution
     def getTrueSolution(self): return self.true_solution

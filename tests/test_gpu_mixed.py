@@ -1,0 +1,57 @@
+"""Config 3: fp32-storage inner CG inside fp64 iterative refinement (dtype F32_MIXED).  The reference
+has no fp32 path, so there is no oracle twin: the pin is the fp64 TRUE residual of the returned x,
+evaluated with the CPU oracle's operator, and closeness to the fp64 solution."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,inner_eps", [(64, 0.0), (256, 0.0), (256, 1e-3), (1024, 0.0)])
+def test_mixed_reaches_fp64_residual(N, inner_eps):
+    import iterative_solvers_amd as isa
+    from oracle.oracle import OracleGrid
+    og = OracleGrid(N, N)
+    b = og.rhs()
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    sol = isa.MatrixFreeSolver(s, b, 1e-8, 10 ** 6)
+    outer = []
+    sol.setIterationCallback(lambda it, p, r, e: outer.append((it, r)))
+    x = sol.solve(inner_eps=inner_eps)
+    res = sol.last_results
+    bn = np.linalg.norm(b)
+    true_rel = np.linalg.norm(b - og.apply(x)) / bn
+    assert res.converged and true_rel <= 1e-8                      # north_star: residual checked against fp64
+    assert res.refine_true_rel == pytest.approx(true_rel, rel=1e-6, abs=1e-13)
+    assert res.refine_outer == len(outer) >= 2                      # fp32 alone cannot reach 1e-8
+    assert [o[0] for o in outer] == sorted(o[0] for o in outer) and outer[-1][0] == res.iterations
+    x64 = isa.MatrixFreeSolver(isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0), b, 1e-8, 10 ** 6).solve()
+    assert np.abs(x - x64).max() <= 1e-6 * np.abs(x64).max()
+
+
+def test_mixed_rejects_msg_rule_and_reports_stagnation_honestly():
+    import iterative_solvers_amd as isa
+    s = isa.GridSystem(32, 32, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-6, 100)
+    with pytest.raises(ValueError):
+        m.solve(None)
+    # an unreachable target: the solver stops when refinement no longer helps and says "not converged"
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-30, 10 ** 5)
+    sol.solve()
+    assert not sol.last_results.converged and sol.last_results.refine_true_rel < 1e-12
+
+
+def test_config3_8192_mixed_full_solve():
+    """BASELINE config 3: N = 8192 (50 315 265 unknowns), fp32 inner CG, fp64 residual <= 1e-8."""
+    import iterative_solvers_amd as isa
+    from oracle.oracle import OracleGrid
+    N = 8192
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    assert s.size() == 50315265
+    b = s.get_rhs()
+    sol = isa.MatrixFreeSolver(s, b, 1e-8, 200000)
+    x = sol.solve()
+    res = sol.last_results
+    assert res.converged and res.refine_true_rel <= 1e-8
+    og = OracleGrid(N, N)                                            # fp64 reference operator on the CPU
+    assert np.linalg.norm(b - og.apply(x)) / np.linalg.norm(b) <= 1e-8
