@@ -561,6 +561,19 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts(const double* part, int
     }
 }
 
+// per-block max |x - u| over the owned range (MSG rule: the error norm of an iteration whose update
+// kernel skipped the u stream because no criterion or callback needed it; msg_solver.cpp:132-139)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_err_maxnorm(long long begin, long long len, const T* x, const T* u, double* part) {
+    __shared__ double lds[kWaves];
+    const long long stride = (long long)gridDim.x * kBlock;
+    double m = 0.0;
+    for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride)
+        m = fmax(m, fabs((double)(x[i] - u[i])));
+    const double t = block_reduce<true>(m, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
 // ---- mixed precision (fp32 inner CG inside fp64 iterative refinement; no reference twin) ------------
 // rf = (float)(b - ax) over the whole stored range (pads/ghosts stay 0) and partial sums of (b - ax)^2
 // over the owned range: forms the fp64 true residual, its norm and the fp32 right-hand side in one pass.

@@ -667,6 +667,11 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     const double initial_rnorm2 = c->summary_h->rnorm2;
     if (msg && cb) cb(user, 0, DBL_MAX, c->summary_h->rmax, cfg.has_u ? c->summary_h->emax : DBL_MAX);   // msg_solver.cpp:75-77
 
+    // The reference recomputes ||x - u|| every iteration (msg_solver.cpp:132-139), but the value is only
+    // observable through the exact-error criterion, the periodic callbacks and the final report: read u
+    // on exactly those iterations (same values), and once more after the loop if the last one skipped it.
+    const int every_cb = prm->callback_every;
+    auto need_u = [&](int it) { return diag || cfg.rp.eps_exact_error > 0 || it == 1 || (every_cb > 0 && it % every_cb == 0); };
     int sync_every = prm->sync_every > 0 ? prm->sync_every : (diag ? 1 : (msg ? 100 : 200));
     sync_every = std::min(sync_every, kHist);
     const int every = prm->callback_every;
@@ -684,7 +689,9 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
             c->cur ^= 1;
             prof_end(c, 0, e0);
             prof_begin(c, 1, &e0);
-            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c));
+            IterCfg ucfg = cfg;
+            ucfg.has_u = cfg.has_u && need_u(it_done + k + 1);      // skip the u stream when nothing reads the error norm
+            launch_update<double, 2>(c, ucfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c));
             prof_end(c, 1, e0);
             if (diag) {
                 // MatrixFreeSolver's per-iteration report: second apply for the TRUE residual
@@ -718,7 +725,15 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         }
         it_done = it_now;
     }
-    const CgState fin = *c->summary_h;
+    CgState fin = *c->summary_h;
+    if (cfg.has_u && fin.it > 0 && !need_u(fin.it)) {
+        hipLaunchKernelGGL((k_err_maxnorm<double>), dim3(1024), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->x, c->u, c->partR);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * 1024, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        double m = 0; for (int i = 0; i < 1024; ++i) m = std::max(m, c->partR_h[i]);
+        fin.emax = m;
+    }
     c->solved = true;
     prof_collect(c);
     mi355cg_results res{};
