@@ -27,7 +27,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured-achievable
 ALG_BYTES_PER_UNKNOWN = 88.0    # 11 words fp64 per unknown per iteration
-KERNEL_ALG_WORDS = {"stencil": 4, "update": 6}   # fused A' = A+C with p ping-pong: read r,p write p,Ap; B: read x,p,r,Ap write x,r
+# compulsory words per unknown and launch.  Default REL_2NORM path: the stencil launch also
+# carries the previous x update (read r,p,x / write p,Ap,x = 6), the update launch is r -= alpha*Ap (read r,Ap / write r = 3).
+# MSG rule or MI355CG_XFUSE=0: stencil 4 (read r,p / write p,Ap), update 6 (read x,p,r,Ap / write x,r).
+KERNEL_ALG_WORDS_XFUSE = {"stencil": 6, "update": 3}
+KERNEL_ALG_WORDS_PLAIN = {"stencil": 4, "update": 6}
 
 
 def unknowns(n: int) -> int:
@@ -119,6 +123,8 @@ def main():
         # same loop again with a HIP-event pair around every launch on the solve stream
         k = min(args.steps, 500)
         run(k, True)
+        xfuse = args.rule == "rel2" and os.environ.get("MI355CG_XFUSE", "1") != "0"
+        KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_XFUSE if xfuse else KERNEL_ALG_WORDS_PLAIN
         t = {name: h.kernel_time(i) for i, name in enumerate(("stencil", "update"))}
         dom = max(t, key=lambda name: t[name][0] * t[name][1])
         ms, launches = t[dom]
@@ -128,7 +134,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
-                    "alg_bytes_per_launch": alg,
+                    "alg_bytes_per_launch": alg, "alg_words_per_unknown": KERNEL_ALG_WORDS[dom],
                     "other": {name: {"avg_ms": round(t[name][0], 5),
                                      "achieved": round(KERNEL_ALG_WORDS[name] * 8.0 * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}
                               for name in t}}

@@ -177,6 +177,7 @@ struct StencilArgs {
     const T* pin;        // FUSED: previous direction; PLAIN: the vector to apply the operator to
     T* pout;             // FUSED: new direction (ping-pong partner of pin)
     T* ap;               // A_h * (new direction | input vector)
+    T* x;                // XUPD: solution vector updated with the previous iteration's step
     const double* partB; int nB, strideB, esB;  // update-kernel partials to reduce in the prologue (count, field stride, element stride)
     double* partA; int strideA, slotA;          // this kernel's partials (field-major); first slot of this launch
     const CgState* s_in; CgState* s_out;        // state written by the update kernel / by this kernel
@@ -186,6 +187,13 @@ struct StencilArgs {
 };
 
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
+
+// Cache-policy experiment knobs for the update kernel (bit mask, wave-uniform; env MI355CG_NT).
+// Non-temporal accesses on the once-per-iteration streams were measured in the real CG loop
+// (profiles/r01_tune_notes.md): no consistent gain at N = 4096, so the default mask is 0.
+enum { NT_B_X = 1, NT_B_AP = 2, NT_B_P = 16, NT_B_R = 32, NT_B_U = 256 };
+template <typename V> __device__ inline V ld_pol(const V* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+template <typename V> __device__ inline void st_pol(V* p, V v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 
 // Work-item decode shared by the stencil and the 2-D update kernel.
 struct Item { int strip, ya, yb; };
@@ -209,7 +217,11 @@ __device__ inline Item decode_item(const WorkList& wl, int item) {
 // lanes load their outside neighbour themselves.  The update kernel marches the same chunks
 // in the opposite direction, so each kernel starts on the rows the previous one touched last
 // (they are still in the 256 MiB Infinity Cache when the vectors are ~100 MB each).
-template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool DESC>
+// XUPD (relative-2-norm rule only): the x update of the PREVIOUS iteration, x += alpha_{k-1} p_{k-1}, rides
+// along here -- p_{k-1} is this kernel's input direction and is in registers anyway -- so the update kernel
+// shrinks to r -= alpha*Ap (3 words) and an iteration moves 9 words per unknown instead of 10.  Element-wise
+// arithmetic and order are unchanged; the last pending x update is flushed by k_flush_x after the loop.
+template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool DESC, bool XUPD = false>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     typedef typename VecOf<T, VEC>::type vec_t;
     __shared__ double lds[kWaves];
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR item decode
 
-    T beta = (T)0;
+    T beta = (T)0, alpha_prev = (T)0;
     if (FUSED) {
         const CgState s = *a.s_in;
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
@@ -225,13 +237,14 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, s, d);
         if (d.done) return;
         beta = (T)d.beta;
+        alpha_prev = (T)s.alpha;          // step length of the iteration whose x update is still pending (0 at the start)
     }
 
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     double acc_pap = 0.0, acc_rz = 0.0;
     constexpr int DIR = DESC ? -1 : 1;
 
-    struct Raw { vec_t r, p; T re, pe; };
+    struct Raw { vec_t r, p, x; T re, pe; };
 
     for (int item = blockIdx.x * kWaves + wave; item < a.wl.nitems; item += gridDim.x * kWaves) {
         const Item it = decode_item(a.wl, item);
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
             vec_t z; for (int j = 0; j < VEC; ++j) z[j] = (T)0;
             w.p = v ? *reinterpret_cast<const vec_t*>(a.pin + off + x) : z;
             if (FUSED) w.r = v ? *reinterpret_cast<const vec_t*>(a.r + off + x) : z; else w.r = z;
+            if (XUPD) w.x = (v && y >= it.ya && y <= it.yb) ? *reinterpret_cast<const vec_t*>(a.x + off + x) : z;
             w.re = (T)0; w.pe = (T)0;
             if (with_edge && edge && xe >= cmin && xe < g.xlim) {
                 w.pe = a.pin[off + xe];
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
 
         Raw q[DEPTH];
         vec_t pn_b, pn_c, pn_a, r_c;       // behind / centre / ahead rows in march order
+        vec_t x_c, pold_c;                 // XUPD: x and the input direction of the centre row
         T pne_c, pne_a, dummy;
         {
             const Raw wb = fetch(ystart - DIR, false);
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
             conv(wb, pn_b, dummy);
             conv(wc, pn_c, pne_c);
             r_c = wc.r;
+            if (XUPD) { x_c = wc.x; pold_c = wc.p; }
         }
 
         for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
@@ -322,8 +338,15 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                         const long long off = row_off(g, y) - g.base0 + x;
                         *reinterpret_cast<vec_t*>(a.ap + off) = out;
                         if (FUSED) *reinterpret_cast<vec_t*>(a.pout + off) = pn_c;
+                        if (XUPD) {
+                            vec_t xn;
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j) xn[j] = x_c[j] + alpha_prev * pold_c[j];   // x = x + alpha*z
+                            *reinterpret_cast<vec_t*>(a.x + off) = xn;
+                        }
                     }
                     pn_b = pn_c; pn_c = pn_a; pne_c = pne_a; r_c = w.r;
+                    if (XUPD) { x_c = w.x; pold_c = w.p; }
                 }
             }
         }
@@ -349,6 +372,8 @@ struct UpdateArgs {
     int rule;                  // MSG: alpha = rz / Azz ; REL2: alpha = rr / pAp
     int init;                  // 1: alpha := 0, state initialisation (x = 0, r = b)
     int reverse;               // flat kernel: sweep the range from its end to its start
+    int nt;                    // NT_B_* cache-policy bits
+    int light;                 // 1: r -= alpha*Ap only (the x update rides in the next stencil launch, see XUPD)
 };
 
 template <typename T, int VEC, bool HAS_U>
@@ -381,10 +406,11 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     const vec_t* Uu = reinterpret_cast<const vec_t*>(a.u);
 
     const long long last = a.begin + a.nvec - 1;
+    const bool nt_x = a.nt & NT_B_X, nt_ap = a.nt & NT_B_AP, nt_p = a.nt & NT_B_P, nt_r = a.nt & NT_B_R, nt_u = a.nt & NT_B_U;
     auto body = [&](long long i_fwd) {
         const long long i = a.reverse ? last - (i_fwd - a.begin) : i_fwd;
-        const vec_t x0 = X[i], pv = Pp[i], r0 = R[i], qv = Q[i];
-        vec_t uv; if (HAS_U) uv = Uu[i];
+        const vec_t x0 = ld_pol(X + i, nt_x), pv = ld_pol(Pp + i, nt_p), r0 = ld_pol(R + i, nt_r), qv = ld_pol(Q + i, nt_ap);
+        vec_t uv; if (HAS_U) uv = ld_pol(Uu + i, nt_u);
         vec_t xn, rn;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -402,12 +428,41 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
                 s_e2 += ee * ee;
             }
         }
-        X[i] = xn; R[i] = rn;
+        st_pol(X + i, xn, nt_x); st_pol(R + i, rn, nt_r);
     };
     long long i = a.begin + (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long end = a.begin + a.nvec;
-    for (; i + stride < end; i += 2 * stride) { body(i); body(i + stride); }
-    if (i < end) body(i);
+    if (a.light) {
+        // r = r - alpha*A_z only (matrix_free_system.cpp:427-429); 4 independent pairs of loads in flight per lane
+        constexpr int U = 4;
+        for (; i < end; i += U * stride) {
+            vec_t r0[U], qv[U];
+            long long idx[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const long long f = i + k * stride;
+                idx[k] = a.reverse ? last - (f - a.begin) : f;
+                if (f < end) { r0[k] = R[idx[k]]; qv[k] = Q[idx[k]]; }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (i + k * stride < end) {
+                    vec_t rn;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        rn[j] = r0[k][j] - alpha * qv[k][j];
+                        const double rd = (double)rn[j];
+                        s_rr += rd * rd;
+                        s_rmax = fmax(s_rmax, fabs(rd));
+                    }
+                    R[idx[k]] = rn;
+                }
+            }
+        }
+    } else {
+        for (; i + stride < end; i += 2 * stride) { body(i); body(i + stride); }
+        if (i < end) body(i);
+    }
 
     const double t_rr = block_reduce<false>(s_rr, lds);
     const double t_rmax = block_reduce<true>(s_rmax, lds);
@@ -559,6 +614,13 @@ __global__ __launch_bounds__(kBlock) void k_reduce_parts(const double* part, int
                                                 : reduce_parts<false>(part + f * stride, n, 1, lds);
         if (threadIdx.x == 0) out[f] = v;
     }
+}
+
+// x += alpha * p over the owned range: the x update still pending when an XUPD loop ends.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_flush_x(long long begin, long long len, T* x, const T* p, T alpha) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride) x[i] = x[i] + alpha * p[i];
 }
 
 // per-block max |x - u| over the owned range (MSG rule: the error norm of an iteration whose update

@@ -68,6 +68,8 @@ struct mi355cg_ctx {
     int grid_int = 0, grid_edge = 0;
     int grid_stencil = 0, grid_update = 0, rows_per_item = 0, depth = 4;
     int update_mode = 1, stencil_desc = 1, update_desc = 0, update_unroll = 4;   // launch-shape knobs (env)
+    int nt_mask = 0;                    // cache-policy bits (NT_*), env MI355CG_NT
+    int xfuse = 1, xdepth = 2;          // REL_2NORM: fold the x update into the next stencil launch (env MI355CG_XFUSE, MI355CG_XDEPTH)
     int strideA = 0, strideB = 0;
     struct Plan { WorkList wl; int grid_stencil = 0, grid_update = 0, rows_per_item = 0; } plan32;   // fp32 kernels (VEC = 4)
 
@@ -177,11 +179,14 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     const int max_upd = std::max(1, env_int("MI355CG_UPDATE_BLOCKS", 512));
     c->update_mode = env_int("MI355CG_UPDATE_MODE", 0);          // 0: flat sweep, 1: 2-D chunks shared with the stencil
     c->stencil_desc = env_int("MI355CG_STENCIL_DESC", 0);        // march direction of the stencil chunks
-    c->update_desc = env_int("MI355CG_UPDATE_DESC", 0);          // sweep direction of the update
+    c->update_desc = env_int("MI355CG_UPDATE_DESC", 1);          // the flat update sweeps from the end: it starts on what the stencil touched last
     c->update_unroll = env_int("MI355CG_UPDATE_UNROLL", 4);
     if (c->update_mode == 1) c->grid_update = std::max(1, std::min(max_upd, (c->wl.nitems + kWaves - 1) / kWaves));
     else c->grid_update = (int)std::max<long long>(1, std::min<long long>(max_upd, (nvec + kBlock - 1) / kBlock));
     c->depth = env_int("MI355CG_DEPTH", 4);
+    c->nt_mask = env_int("MI355CG_NT", 0);
+    c->xfuse = env_int("MI355CG_XFUSE", 1);
+    c->xdepth = env_int("MI355CG_XDEPTH", 2);
 }
 
 PackGeom pack_geom(const mi355cg_ctx* c) {
@@ -211,6 +216,15 @@ void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a, const S
     if (c->stencil_desc) launch_stencil_dir<T, VEC, FUSED, MSG, true>(c, a, w);
     else launch_stencil_dir<T, VEC, FUSED, MSG, false>(c, a, w);
 }
+// fused stencil that also applies the previous iteration's x update (REL_2NORM fast path)
+template <typename T, int VEC>
+void launch_stencil_xupd(const mi355cg_ctx* c, const StencilArgs<T>& a, const StencilWhere& w) {
+    dim3 grid(w.grid), block(kBlock);
+    // 2 rows in flight: with the extra x stream 4 rows need 138 VGPRs (3 waves/SIMD, the 4096-wave grid no
+    // longer fits at once); 2 rows need 104 (4 waves/SIMD) and measured 5 % faster (profiles/r01_tune_notes.md)
+    if (c->xdepth == 4) hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 4, false, true>), grid, block, 0, w.stream, a);
+    else hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 2, false, true>), grid, block, 0, w.stream, a);
+}
 
 template <typename T, int VEC>
 StencilArgs<T> stencil_args_common(const mi355cg_ctx* c, const StencilWhere& w) {
@@ -230,18 +244,19 @@ void launch_apply(const mi355cg_ctx* c, const T* v, T* out) {
     launch_stencil_depth<T, VEC, false, false>(c, a, w);
 }
 
-struct IterCfg { RuleParams rp; int want_diag; bool has_u; };
+struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool xfuse = false; };
 
 // Phase A'.  Does NOT flip c->cur (a slab's interior and edge launches share one direction pair).
 template <typename T, int VEC>
 void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], T* ap,
-                              const StencilWhere& w, const PartSrc& pb) {
+                              const StencilWhere& w, const PartSrc& pb, T* x = nullptr) {
     StencilArgs<T> a = stencil_args_common<T, VEC>(c, w);
     a.r = r; a.pin = p[c->cur]; a.pout = p[c->cur ^ 1]; a.ap = ap;
     a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
     a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slotA;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a, w);
+    else if (cfg.xfuse) { a.x = x; launch_stencil_xupd<T, VEC>(c, a, w); }
     else launch_stencil_depth<T, VEC, true, false>(c, a, w);
 }
 PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, c->grid_update, c->strideB, 1}; }
@@ -255,9 +270,10 @@ void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, c
     a.x = x; a.r = r; a.p = p; a.ap = ap; a.u = u;
     a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
     a.partB = c->partB; a.strideB = c->strideB;
-    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = c->update_desc;
+    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = c->update_desc; a.nt = init ? 0 : c->nt_mask;
+    a.light = (!init && cfg.xfuse) ? 1 : 0;
     dim3 grid(c->grid_update), block(kBlock);
-    if (c->update_mode == 1) {
+    if (c->update_mode == 1 && !a.light) {
         Update2DArgs<T> aa{};
         aa.g = c->g; aa.g.xlim = (int)round_up(c->g.N + 1, VEC); aa.wl = c->wl; aa.u = a;
 #define MI355CG_U2D(HASU, UNR, DESC) hipLaunchKernelGGL((k_update2d<T, VEC, HASU, UNR, DESC>), grid, block, 0, stream, aa)
@@ -638,8 +654,9 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     HIPCK(hipSetDevice(c->device));
     if (c->dtype == MI355CG_F32_MIXED) return solve_mixed(c, prm, cb, user, stop_flag, out);
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
-    const IterCfg cfg = make_cfg(prm);
+    IterCfg cfg = make_cfg(prm);
     const bool diag = cfg.want_diag != 0;
+    cfg.xfuse = c->xfuse && !msg && !diag && !cfg.has_u && c->update_mode == 0;     // 9-word iteration
     if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -685,7 +702,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         for (int k = 0; k < m; ++k) {
             hipEvent_t e0 = nullptr;
             prof_begin(c, 0, &e0);
-            launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, whole_slab(c), own_partB(c));
+            launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, whole_slab(c), own_partB(c), c->x);
             c->cur ^= 1;
             prof_end(c, 0, e0);
             prof_begin(c, 1, &e0);
@@ -726,6 +743,15 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         it_done = it_now;
     }
     CgState fin = *c->summary_h;
+    // Launches enqueued after the stop decision return in their prologue but still flipped c->cur on the
+    // host: the direction of the last REAL iteration is p[it % 2] (the solve starts with cur = 0).
+    c->cur = fin.it & 1;
+    if (cfg.xfuse && fin.it > 0) {      // the last iteration's x += alpha*p has not been applied yet
+        hipLaunchKernelGGL((k_flush_x<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream,
+                           c->g.own_begin, c->g.own_len, c->x, c->p[c->cur], fin.alpha);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(c->stream));
+    }
     if (cfg.has_u && fin.it > 0 && !need_u(fin.it)) {
         hipLaunchKernelGGL((k_err_maxnorm<double>), dim3(1024), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->x, c->u, c->partR);
         HIPCK(hipGetLastError());

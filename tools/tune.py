@@ -28,20 +28,17 @@ def run(env):
     h.set_profiling(True); h.solve(p); h.set_profiling(False)
     ts, tu = h.kernel_time(0)[0], h.kernel_time(1)[0]
     lay = h.layout()
-    print(f"{env} its/s={ITERS/dt:8.1f} GB/s(88B)={88*U*ITERS/dt/1e9:7.1f} stencil={ts*1e3:7.1f}us ({32*U/ts/1e6:6.0f} GB/s) "
-          f"update={tu*1e3:7.1f}us ({48*U/tu/1e6:6.0f} GB/s) grid={lay['grid_stencil']}/{lay['grid_update']} ty={lay['rows_per_item']}", flush=True)
+    print(f"{env} its/s={ITERS/dt:8.1f} GB/s(88B)={88*U*ITERS/dt/1e9:7.1f} stencil={ts*1e3:7.1f}us ({(32 if os.environ.get('MI355CG_XFUSE')=='0' else 48)*U/ts/1e6:6.0f} GB/s) "
+          f"update={tu*1e3:7.1f}us ({(48 if os.environ.get('MI355CG_XFUSE')=='0' else 24)*U/tu/1e6:6.0f} GB/s) grid={lay['grid_stencil']}/{lay['grid_update']} ty={lay['rows_per_item']}", flush=True)
     h.close()
 
 
 if __name__ == "__main__":
-    base = {"MI355CG_STENCIL_WAVES": 4096, "MI355CG_STENCIL_BLOCKS": 1024, "MI355CG_DEPTH": 4, "MI355CG_UPDATE_BLOCKS": 1024,
-            "MI355CG_UPDATE_MODE": 0, "MI355CG_STENCIL_DESC": 0, "MI355CG_UPDATE_DESC": 0, "MI355CG_UPDATE_UNROLL": 4, "MI355CG_ROWS": 0}
-    run(base)
-    run({**base, "MI355CG_UPDATE_DESC": 1})
-    for rows in (6, 8, 12, 16):
-        for blocks in (512, 1024, 2048):
-            run({**base, "MI355CG_ROWS": rows, "MI355CG_STENCIL_BLOCKS": blocks, "MI355CG_UPDATE_DESC": 1})
-        run({**base, "MI355CG_ROWS": rows, "MI355CG_UPDATE_DESC": 0})
-    run({**base, "MI355CG_ROWS": 8, "MI355CG_UPDATE_DESC": 1, "MI355CG_DEPTH": 2})
-    run({**base, "MI355CG_ROWS": 8, "MI355CG_UPDATE_DESC": 1, "MI355CG_UPDATE_BLOCKS": 512})
-    run({**base, "MI355CG_ROWS": 8, "MI355CG_UPDATE_DESC": 1, "MI355CG_UPDATE_BLOCKS": 2048})
+    z = {"MI355CG_XFUSE": 1, "MI355CG_DEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_UPDATE_BLOCKS": 512, "MI355CG_UPDATE_DESC": 1}
+    run(z)
+    run({**z, "MI355CG_UPDATE_DESC": 0})
+    run({**z, "MI355CG_UPDATE_DESC": 0, "MI355CG_UPDATE_BLOCKS": 1024})
+    run({**z, "MI355CG_UPDATE_DESC": 1, "MI355CG_DEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
+    run({**z, "MI355CG_UPDATE_DESC": 0, "MI355CG_DEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
+    run({**z, "MI355CG_NT": 2}); run({**z, "MI355CG_NT": 32}); run({**z, "MI355CG_NT": 34})
+    run(z)
