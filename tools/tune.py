@@ -34,11 +34,10 @@ def run(env):
 
 
 if __name__ == "__main__":
-    z = {"MI355CG_XFUSE": 1, "MI355CG_DEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_UPDATE_BLOCKS": 512, "MI355CG_UPDATE_DESC": 1}
-    run(z)
-    run({**z, "MI355CG_UPDATE_DESC": 0})
-    run({**z, "MI355CG_UPDATE_DESC": 0, "MI355CG_UPDATE_BLOCKS": 1024})
-    run({**z, "MI355CG_UPDATE_DESC": 1, "MI355CG_DEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
-    run({**z, "MI355CG_UPDATE_DESC": 0, "MI355CG_DEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
-    run({**z, "MI355CG_NT": 2}); run({**z, "MI355CG_NT": 32}); run({**z, "MI355CG_NT": 34})
-    run(z)
+    z = {"MI355CG_XFUSE": 1, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_ZIGZAG": 0}
+    for rep in range(2):
+        run(z)
+        run({**z, "MI355CG_ZIGZAG": 1})
+    run({**z, "MI355CG_ZIGZAG": 1, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
+    run({**z, "MI355CG_ZIGZAG": 1, "MI355CG_STENCIL_WAVES": 8192})
+    run({**z, "MI355CG_ZIGZAG": 0, "MI355CG_STENCIL_WAVES": 8192})
