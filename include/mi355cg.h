@@ -156,6 +156,7 @@ int  mi355cg_dist_flip(mi355cg_handle h);          /* once per stencil phase: ne
 int  mi355cg_dist_update(mi355cg_handle h, const double *gathered_stencil_sums, int nranks, int estride, void *stream);
 int  mi355cg_dist_check(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride, void *stream);
 int  mi355cg_dist_summary(mi355cg_handle h, mi355cg_results *out, int *done);   /* after a stream sync */
+int  mi355cg_dist_finish(mi355cg_handle h, void *stream);   /* once after the loop: flush the pending x update */
 int  mi355cg_dist_history(mi355cg_handle h, int iteration, double *precision, double *residual, double *error);
 int  mi355cg_dist_halo(mi355cg_handle h, int vector /*0 r, 1 current direction*/,
                        void **send_lo, void **recv_lo, long long *n_send_lo,

@@ -414,7 +414,7 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
         for (int k = 0; k < m; ++k) {
             hipEvent_t e0 = nullptr;
             prof_begin(c, 0, &e0);
-            launch_iteration_stencil<float, 4>(c, cfg, c->rf, c->pf, c->apf, whole_slab(c), own_partB(c));
+            launch_iteration_stencil<float, 4>(c, cfg, c->rf, c->pf, c->apf, whole_slab(c), own_partB(c), c->xf);
             c->cur ^= 1;
             prof_end(c, 0, e0);
             prof_begin(c, 1, &e0);
@@ -426,6 +426,12 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
         done_its = c->summary_h->it;
     }
     *its = c->summary_h->it;
+    c->cur = *its & 1;
+    if (cfg.xfuse && *its > 0) {        // the last inner iteration's x += alpha*p is still pending
+        hipLaunchKernelGGL((k_flush_x<float>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream,
+                           c->g.own_begin, c->g.own_len, c->xf, c->pf[c->cur], (float)c->summary_h->alpha);
+        HIPCK(hipGetLastError());
+    }
     return MI355CG_OK;
 }
 
@@ -459,7 +465,8 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
     while (!converged && total < prm->max_iterations && !interrupted) {
         mi355cg_params ip = *prm;
         ip.eps_rel = inner_eps; ip.max_iterations = prm->max_iterations - total; ip.diagnostics = 0;
-        const IterCfg cfg = make_cfg(&ip);
+        IterCfg cfg = make_cfg(&ip);
+        cfg.xfuse = c->xfuse && c->update_mode == 0;
         int its = 0;
         if (int rc = inner_cg_f32(c, cfg, sync_every, stop_flag, &its, &interrupted)) return rc;
         total += its; ++outer;
@@ -859,6 +866,12 @@ int mi355cg_owned_range(mi355cg_handle c, long long* packed_begin, long long* pa
 // The dist entry points enqueue on the caller's stream, taken literally (NULL = HIP's default stream,
 // which is also torch's default stream), so they order with the caller's collectives and copies.
 static hipStream_t pick_stream(mi355cg_ctx*, void* stream) { return (hipStream_t)stream; }
+// Slab-mode iteration config: the 9-word path (x update folded into the stencil) whenever the rule allows it.
+static IterCfg dist_cfg(const mi355cg_ctx* c) {
+    IterCfg cfg = make_cfg(&c->dist_prm);
+    cfg.xfuse = c->xfuse && c->update_mode == 0 && c->dist_prm.rule == MI355CG_RULE_REL_2NORM && !cfg.has_u;
+    return cfg;
+}
 
 int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream) {
     if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
@@ -866,7 +879,7 @@ int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream
     if (prm->diagnostics) return fail(MI355CG_ERR_INVALID, "per-iteration diagnostics are not available in slab mode");
     HIPCK(hipSetDevice(c->device));
     c->dist_prm = *prm; c->dist_active = true;
-    const IterCfg cfg = make_cfg(prm);
+    const IterCfg cfg = dist_cfg(c);
     if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
     hipStream_t st = pick_stream(c, stream);
     const size_t bytes = sizeof(double) * c->storage_len;
@@ -941,13 +954,13 @@ int mi355cg_dist_scatter_ghosts(mi355cg_handle c, int vector, const double* gath
 // `estride` = doubles between consecutive ranks' sums in `gathered_B` (FB_COUNT, or the record width).
 int mi355cg_dist_stencil(mi355cg_handle c, const double* gathered_B, int nranks, int estride, int rows, void* stream) {
     if (!c || !c->dist_active || !gathered_B) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
-    const IterCfg cfg = make_cfg(&c->dist_prm);
+    const IterCfg cfg = dist_cfg(c);
     StencilWhere w{pick_stream(c, stream), &c->wl, c->grid_stencil, 0};
     if (rows == 1) w = StencilWhere{w.stream, &c->wl_int, c->grid_int, 0};
     else if (rows == 2) w = StencilWhere{w.stream, &c->wl_edge, c->grid_edge, c->grid_int};
     if (rows == 1 && c->wl_int.nitems == 0) return MI355CG_OK;
     const PartSrc pb{gathered_B, nranks, 1, estride};
-    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, w, pb);
+    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, w, pb, c->x);
     c->nA_dist = rows == 0 ? c->grid_stencil : c->grid_int + c->grid_edge;
     HIPCK(hipGetLastError());
     return MI355CG_OK;
@@ -959,7 +972,7 @@ int mi355cg_dist_flip(mi355cg_handle c) {
 }
 int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, int estride, void* stream) {
     if (!c || !c->dist_active || !gathered_A) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
-    const IterCfg cfg = make_cfg(&c->dist_prm);
+    const IterCfg cfg = dist_cfg(c);
     const PartSrc pa{gathered_A, nranks, 1, estride};
     launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, pick_stream(c, stream), pa);
     HIPCK(hipGetLastError());
@@ -973,6 +986,20 @@ int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, i
     launch_check(c, cfg, st, PartSrc{gathered_B, nranks, 1, estride});
     HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, st));
     HIPCK(hipMemcpyAsync(c->hist_h, c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, st));
+    return MI355CG_OK;
+}
+// Call once after the loop (after the last mi355cg_dist_check has been synchronised): applies the x update
+// that is still pending when the 9-word path is active.  No-op otherwise.
+int mi355cg_dist_finish(mi355cg_handle c, void* stream) {
+    if (!c || !c->dist_active) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run");
+    const IterCfg cfg = dist_cfg(c);
+    const CgState fin = *c->summary_h;
+    c->cur = fin.it & 1;                 // launches after the stop decision were no-ops but flipped the host-side index
+    if (cfg.xfuse && fin.it > 0) {
+        hipLaunchKernelGGL((k_flush_x<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, pick_stream(c, stream),
+                           c->g.own_begin, c->g.own_len, c->x, c->p[c->cur], fin.alpha);
+        HIPCK(hipGetLastError());
+    }
     return MI355CG_OK;
 }
 int mi355cg_dist_summary(mi355cg_handle c, mi355cg_results* out, int* done) {

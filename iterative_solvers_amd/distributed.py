@@ -142,6 +142,9 @@ class SlabEngine:
         _capi.check(self._lib.mi355cg_dist_summary(self._h, C.byref(res), C.byref(done)))
         return res, bool(done.value)
 
+    def finish(self):
+        _capi.check(self._lib.mi355cg_dist_finish(self._h, self._stream()))
+
     def history(self, it: int):
         p, r, e = C.c_double(), C.c_double(), C.c_double()
         _capi.check(self._lib.mi355cg_dist_history(self._h, it, C.byref(p), C.byref(r), C.byref(e)))
@@ -323,6 +326,7 @@ class DistributedCG:
                         callback(it, *eng.history(it))
             it_done = res.iterations
         comm.halo_wait(tok_r); comm.halo_wait(tok_p)
+        eng.finish()                                        # flush the x update still pending on the 9-word path
         if msg and callback:
             callback(res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm)
         return DistResults(res.iterations, bool(res.converged), res.stop_reason, res.final_residual_norm,

@@ -194,6 +194,9 @@ class OracleSlabEngine:
         res.r_norm2, res.initial_r_norm2 = s["rnorm2"], s["r0norm"]
         return res, bool(s["done"])
 
+    def finish(self):
+        pass
+
     def history(self, it: int):
         d, r, e = self.hist[it]
         return d, r, (e if self.use_u else DBL_MAX)
