@@ -178,6 +178,8 @@ struct StencilArgs {
     T* pout;             // FUSED: new direction (ping-pong partner of pin)
     T* ap;               // A_h * (new direction | input vector)
     T* x;                // XUPD: solution vector updated with the previous iteration's step
+    const T* zero;       // >= 16 bytes of zeros: what lanes / rows without data load
+    T* trash;            // >= 16 bytes nobody reads: where lanes outside the stored columns store
     const double* partB; int nB, strideB, esB;  // update-kernel partials to reduce in the prologue (count, field stride, element stride)
     double* partA; int strideA, slotA;          // this kernel's partials (field-major); first slot of this launch
     const CgState* s_in; CgState* s_out;        // state written by the update kernel / by this kernel
@@ -255,20 +257,21 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         const int nrows = it.yb - it.ya + 1;
         const int ystart = DESC ? it.yb : it.ya;
 
-        auto fetch = [&](int y, bool with_edge) -> Raw {
+        // Branch-free loads: a lane (or a whole row) that has nothing to load reads the 16-byte zero
+        // block instead, so there is no exec-masked region around any load and hipcc can wait with
+        // counted vmcnt(N) -- the rows prefetched for later iterations really stay in flight.
+        auto fetch = [&](int y, bool with_edge, bool row_ok) -> Raw {
             Raw w;
             const int cmin = y <= g.half ? g.cb : 0;
             const long long off = row_off(g, y) - g.base0;
-            const bool v = xin && x >= cmin;
-            vec_t z; for (int j = 0; j < VEC; ++j) z[j] = (T)0;
-            w.p = v ? *reinterpret_cast<const vec_t*>(a.pin + off + x) : z;
-            if (FUSED) w.r = v ? *reinterpret_cast<const vec_t*>(a.r + off + x) : z; else w.r = z;
-            if (XUPD) w.x = (v && y >= it.ya && y <= it.yb) ? *reinterpret_cast<const vec_t*>(a.x + off + x) : z;
-            w.re = (T)0; w.pe = (T)0;
-            if (with_edge && edge && xe >= cmin && xe < g.xlim) {
-                w.pe = a.pin[off + xe];
-                if (FUSED) w.re = a.r[off + xe];
-            }
+            const bool v = row_ok && xin && x >= cmin;
+            w.p = *reinterpret_cast<const vec_t*>(v ? a.pin + off + x : a.zero);
+            if (FUSED) w.r = *reinterpret_cast<const vec_t*>(v ? a.r + off + x : a.zero);
+            else for (int j = 0; j < VEC; ++j) w.r[j] = (T)0;
+            if (XUPD) w.x = *reinterpret_cast<const vec_t*>((v && y >= it.ya && y <= it.yb) ? a.x + off + x : a.zero);
+            const bool ev = row_ok && with_edge && edge && xe >= cmin && xe < g.xlim;
+            w.pe = *(ev ? a.pin + off + xe : a.zero);
+            if (FUSED) w.re = *(ev ? a.r + off + xe : a.zero); else w.re = (T)0;
             return w;
         };
         auto conv = [&](const Raw& w, vec_t& pn, T& pne) {
@@ -284,13 +287,10 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         vec_t x_c, pold_c;                 // XUPD: x and the input direction of the centre row
         T pne_c, pne_a, dummy;
         {
-            const Raw wb = fetch(ystart - DIR, false);
-            const Raw wc = fetch(ystart, true);
+            const Raw wb = fetch(ystart - DIR, false, true);
+            const Raw wc = fetch(ystart, true, true);
 #pragma unroll
-            for (int k = 0; k < DEPTH; ++k) {
-                if (k + 1 <= nrows) q[k] = fetch(ystart + DIR * (k + 1), true);
-                else { Raw zz; for (int j = 0; j < VEC; ++j) { zz.r[j] = (T)0; zz.p[j] = (T)0; } zz.re = zz.pe = (T)0; q[k] = zz; }
-            }
+            for (int k = 0; k < DEPTH; ++k) q[k] = fetch(ystart + DIR * (k + 1), true, k + 1 <= nrows);
             conv(wb, pn_b, dummy);
             conv(wc, pn_c, pne_c);
             r_c = wc.r;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                 if (i < nrows) {
                     const int y = ystart + DIR * i;
                     const Raw w = q[k];
-                    if (i + 1 + DEPTH <= nrows) q[k] = fetch(ystart + DIR * (i + 1 + DEPTH), true);
+                    q[k] = fetch(ystart + DIR * (i + 1 + DEPTH), true, i + 1 + DEPTH <= nrows);
                     conv(w, pn_a, pne_a);
 
                     // in-row neighbours: from the adjacent lane, wave-edge lanes use their edge load
@@ -334,15 +334,16 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                         acc_pap += (double)c * (double)out[j];
                         if (MSG) acc_rz += (double)r_c[j] * (double)c;
                     }
-                    if (xin && x >= cmin) {
+                    {   // branch-free stores: lanes outside the stored columns write the trash block
+                        const bool sv = xin && x >= cmin;
                         const long long off = row_off(g, y) - g.base0 + x;
-                        *reinterpret_cast<vec_t*>(a.ap + off) = out;
-                        if (FUSED) *reinterpret_cast<vec_t*>(a.pout + off) = pn_c;
+                        *reinterpret_cast<vec_t*>(sv ? a.ap + off : a.trash) = out;
+                        if (FUSED) *reinterpret_cast<vec_t*>(sv ? a.pout + off : a.trash) = pn_c;
                         if (XUPD) {
                             vec_t xn;
 #pragma unroll
                             for (int j = 0; j < VEC; ++j) xn[j] = x_c[j] + alpha_prev * pold_c[j];   // x = x + alpha*z
-                            *reinterpret_cast<vec_t*>(a.x + off) = xn;
+                            *reinterpret_cast<vec_t*>(sv ? a.x + off : a.trash) = xn;
                         }
                     }
                     pn_b = pn_c; pn_c = pn_a; pne_c = pne_a; r_c = w.r;

@@ -77,6 +77,7 @@ struct mi355cg_ctx {
     double *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
     float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr, *bf = nullptr;
     double* packed = nullptr;           // device scratch, pk_len doubles
+    double *zero_blk = nullptr, *trash_blk = nullptr;   // 256 B each: all-zero source / write-only sink for masked lanes
     double *partA = nullptr, *partB = nullptr, *partR = nullptr;
     double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's record = reduced partials [+ its two boundary rows] (feeds the all-gather)
     int rec_width = 0;
@@ -231,6 +232,7 @@ StencilArgs<T> stencil_args_common(const mi355cg_ctx* c, const StencilWhere& w) 
     StencilArgs<T> a{};
     a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC);
     a.wl = *w.wl;
+    a.zero = reinterpret_cast<const T*>(c->zero_blk); a.trash = reinterpret_cast<T*>(c->trash_blk);
     return a;
 }
 StencilWhere whole_slab(const mi355cg_ctx* c) { return StencilWhere{c->stream, &c->wl, c->grid_stencil, 0}; }
@@ -548,6 +550,7 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
         }
     }
     if ((rc = alloc_vec(&c->packed, std::max<long long>(c->pk_len, 1)))) return cleanup();
+    if ((rc = alloc_vec(&c->zero_blk, 32)) || (rc = alloc_vec(&c->trash_blk, 32))) return cleanup();
     if ((rc = alloc_vec(&c->partA, (long long)FA_COUNT * c->strideA))) return cleanup();
     if ((rc = alloc_vec(&c->partB, (long long)FB_COUNT * c->strideB))) return cleanup();
     if ((rc = alloc_vec(&c->partR, 2048))) return cleanup();
@@ -584,7 +587,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->xf, c->rf, c->pf[0], c->pf[1], c->apf, c->bf,
-                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
+                   c->packed, c->zero_blk, c->trash_blk, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
     for (void* p : dev) if (p) hipFree(p);
     if (c->summary_h) hipHostFree(c->summary_h);
     if (c->hist_h) hipHostFree(c->hist_h);

@@ -34,10 +34,12 @@ def run(env):
 
 
 if __name__ == "__main__":
-    z = {"MI355CG_XFUSE": 1, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_ZIGZAG": 0}
-    for rep in range(2):
-        run(z)
-        run({**z, "MI355CG_ZIGZAG": 1})
-    run({**z, "MI355CG_ZIGZAG": 1, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
-    run({**z, "MI355CG_ZIGZAG": 1, "MI355CG_STENCIL_WAVES": 8192})
-    run({**z, "MI355CG_ZIGZAG": 0, "MI355CG_STENCIL_WAVES": 8192})
+    z = {"MI355CG_XFUSE": 1, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_DEPTH": 4}
+    run(z); run(z)
+    run({**z, "MI355CG_XDEPTH": 4})
+    run({**z, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
+    run({**z, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 3072})
+    run({**z, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 2048})
+    run({**z, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 2048})
+    run({**z, "MI355CG_XFUSE": 0}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_DEPTH": 2}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_DEPTH": 8, "MI355CG_STENCIL_WAVES": 2048})
+    run(z)
