@@ -400,18 +400,15 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
 
     double s_rr = 0, s_rmax = 0, s_dmax = 0, s_emax = 0, s_d2 = 0, s_e2 = 0;
     const long long stride = (long long)gridDim.x * kBlock;
-    vec_t* X = reinterpret_cast<vec_t*>(a.x);
-    vec_t* R = reinterpret_cast<vec_t*>(a.r);
-    const vec_t* Pp = reinterpret_cast<const vec_t*>(a.p);
-    const vec_t* Q = reinterpret_cast<const vec_t*>(a.ap);
-    const vec_t* Uu = reinterpret_cast<const vec_t*>(a.u);
+    vec_t* __restrict__ X = reinterpret_cast<vec_t*>(a.x);                 // five distinct vectors: no aliasing
+    vec_t* __restrict__ R = reinterpret_cast<vec_t*>(a.r);
+    const vec_t* __restrict__ Pp = reinterpret_cast<const vec_t*>(a.p);
+    const vec_t* __restrict__ Q = reinterpret_cast<const vec_t*>(a.ap);
+    const vec_t* __restrict__ Uu = reinterpret_cast<const vec_t*>(a.u);
 
     const long long last = a.begin + a.nvec - 1;
     const bool nt_x = a.nt & NT_B_X, nt_ap = a.nt & NT_B_AP, nt_p = a.nt & NT_B_P, nt_r = a.nt & NT_B_R, nt_u = a.nt & NT_B_U;
-    auto body = [&](long long i_fwd) {
-        const long long i = a.reverse ? last - (i_fwd - a.begin) : i_fwd;
-        const vec_t x0 = ld_pol(X + i, nt_x), pv = ld_pol(Pp + i, nt_p), r0 = ld_pol(R + i, nt_r), qv = ld_pol(Q + i, nt_ap);
-        vec_t uv; if (HAS_U) uv = ld_pol(Uu + i, nt_u);
+    auto elem = [&](long long i, const vec_t& x0, const vec_t& pv, const vec_t& r0, const vec_t& qv, const vec_t& uv) {
         vec_t xn, rn;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -431,37 +428,60 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
         }
         st_pol(X + i, xn, nt_x); st_pol(R + i, rn, nt_r);
     };
+    auto body = [&](long long i_fwd) {
+        const long long i = a.reverse ? last - (i_fwd - a.begin) : i_fwd;
+        const vec_t x0 = ld_pol(X + i, nt_x), pv = ld_pol(Pp + i, nt_p), r0 = ld_pol(R + i, nt_r), qv = ld_pol(Q + i, nt_ap);
+        vec_t uv; if (HAS_U) uv = ld_pol(Uu + i, nt_u);
+        elem(i, x0, pv, r0, qv, uv);
+    };
     long long i = a.begin + (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long end = a.begin + a.nvec;
+    auto at = [&](long long f) { return a.reverse ? last - (f - a.begin) : f; };
     if (a.light) {
-        // r = r - alpha*A_z only (matrix_free_system.cpp:427-429); 4 independent pairs of loads in flight per lane
+        // r = r - alpha*A_z only (matrix_free_system.cpp:427-429).  Full groups first: all loads of a group are
+        // issued before any store (no bounds branch inside), so 8 x 16 B per lane are in flight.
         constexpr int U = 4;
-        for (; i < end; i += U * stride) {
+        for (; i + (U - 1) * stride < end; i += U * stride) {
             vec_t r0[U], qv[U];
-            long long idx[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) { const long long j = at(i + k * stride); r0[k] = R[j]; qv[k] = Q[j]; }
+            __builtin_amdgcn_sched_barrier(0);      // keep all 2U loads ahead of the arithmetic (hipcc otherwise re-interleaves them)
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const long long f = i + k * stride;
-                idx[k] = a.reverse ? last - (f - a.begin) : f;
-                if (f < end) { r0[k] = R[idx[k]]; qv[k] = Q[idx[k]]; }
-            }
+                vec_t rn;
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                if (i + k * stride < end) {
-                    vec_t rn;
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        rn[j] = r0[k][j] - alpha * qv[k][j];
-                        const double rd = (double)rn[j];
-                        s_rr += rd * rd;
-                        s_rmax = fmax(s_rmax, fabs(rd));
-                    }
-                    R[idx[k]] = rn;
+                for (int j = 0; j < VEC; ++j) {
+                    rn[j] = r0[k][j] - alpha * qv[k][j];
+                    const double rd = (double)rn[j];
+                    s_rr += rd * rd;
+                    s_rmax = fmax(s_rmax, fabs(rd));
                 }
+                R[at(i + k * stride)] = rn;
             }
         }
+        for (; i < end; i += stride) {
+            const long long j2 = at(i);
+            const vec_t r0 = R[j2], qv = Q[j2];
+            vec_t rn;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                rn[j] = r0[j] - alpha * qv[j];
+                const double rd = (double)rn[j];
+                s_rr += rd * rd;
+                s_rmax = fmax(s_rmax, fabs(rd));
+            }
+            R[j2] = rn;
+        }
     } else {
-        for (; i + stride < end; i += 2 * stride) { body(i); body(i + stride); }
+        // two elements per lane and trip: both sets of loads are issued before the first store
+        for (; i + stride < end; i += 2 * stride) {
+            const long long j0 = at(i), j1 = at(i + stride);
+            const vec_t xa = ld_pol(X + j0, nt_x), pa = ld_pol(Pp + j0, nt_p), ra = ld_pol(R + j0, nt_r), qa = ld_pol(Q + j0, nt_ap);
+            const vec_t xb = ld_pol(X + j1, nt_x), pb = ld_pol(Pp + j1, nt_p), rb = ld_pol(R + j1, nt_r), qb = ld_pol(Q + j1, nt_ap);
+            vec_t ua, ub; if (HAS_U) { ua = ld_pol(Uu + j0, nt_u); ub = ld_pol(Uu + j1, nt_u); }
+            elem(j0, xa, pa, ra, qa, ua);
+            elem(j1, xb, pb, rb, qb, ub);
+        }
         if (i < end) body(i);
     }
 

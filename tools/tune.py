@@ -34,12 +34,9 @@ def run(env):
 
 
 if __name__ == "__main__":
-    z = {"MI355CG_XFUSE": 1, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_DEPTH": 4}
+    z = {"MI355CG_XFUSE": 1, "MI355CG_UPDATE_BLOCKS": 512}
     run(z); run(z)
-    run({**z, "MI355CG_XDEPTH": 4})
-    run({**z, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 3072})
-    run({**z, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 3072})
-    run({**z, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 2048})
-    run({**z, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 2048})
-    run({**z, "MI355CG_XFUSE": 0}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_DEPTH": 2}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_DEPTH": 8, "MI355CG_STENCIL_WAVES": 2048})
+    for ub in (256, 384, 768, 1024, 2048):
+        run({**z, "MI355CG_UPDATE_BLOCKS": ub})
+    run({**z, "MI355CG_XFUSE": 0}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_UPDATE_BLOCKS": 1024}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_UPDATE_BLOCKS": 256})
     run(z)
