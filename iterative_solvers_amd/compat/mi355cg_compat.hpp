@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <fstream>
 #include <functional>
 #include <iomanip>
@@ -309,14 +310,35 @@ public:
         mi355cg_compat::check(mi355cg_get_solution(h, x.data()));
         return x;
     }
-    // Report text is a "next" row; kept to a plain summary so callers link.
+    // Same sections, labels and number formats as msg_solver.cpp:261-304 (the text is user-facing output).
     std::string generateReport(int n, int m, double a_, double b_, double c_, double d_) const {
-        std::ostringstream os;
-        os << getName() << "\nn = " << n << ", m = " << m << ", [" << a_ << ", " << b_ << "] x [" << c_ << ", " << d_ << "]\n"
-           << "iterations = " << iterations << ", converged = " << (converged ? "yes" : "no") << "\n" << getStopReasonText() << "\n"
-           << std::scientific << "||r||_inf = " << final_residual_norm << ", ||x_n - x_{n-1}||_inf = " << final_precision
-           << ", ||x - u||_inf = " << final_error_norm << "\n";
-        return os.str();
+        std::stringstream ss;
+        ss << "ОТЧЕТ О РЕШЕНИИ ЗАДАЧИ ДИРИХЛЕ\n===========================\n\n";
+        ss << "ПАРАМЕТРЫ ЗАДАЧИ:\n----------------\n";
+        ss << "Размер сетки: " << n << "x" << m << " внутренних узлов\n";
+        ss << "Область: [" << a_ << ", " << b_ << "] x [" << c_ << ", " << d_ << "]\n";
+        ss << "Шаг по x: " << (b_ - a_) / (n + 1) << "\n";
+        ss << "Шаг по y: " << (d_ - c_) / (m + 1) << "\n";
+        ss << "Общее количество неизвестных: " << n * m << "\n\n";
+        ss << "МЕТОД РЕШЕНИЯ:\n-------------\n";
+        ss << "Название метода: " << name << "\n";
+        ss << "Максимальное число итераций: " << maxIterations << "\n";
+        ss << "Критерии остановки:\n";
+        ss << "  - Точность ||xn-x(n-1)||: " << eps_precision << "\n";
+        ss << "  - Норма невязки ||Ax-b||: " << eps_residual << "\n";
+        ss << "  - Норма ошибки ||u-x||: " << eps_exact_error << "\n\n";
+        ss << "РЕЗУЛЬТАТЫ РЕШЕНИЯ:\n-----------------\n";
+        ss << "Выполнено итераций: " << iterations << "\n";
+        ss << "Сходимость: " << (converged ? "Да" : "Нет") << "\n";
+        ss << "Причина остановки: " << getStopReasonText() << "\n";
+        ss << "Достигнутые величины:\n";
+        ss << "  - Точность ||xn-x(n-1)||: " << std::scientific << final_precision << "\n";
+        ss << "  - Норма невязки ||Ax-b||: " << std::scientific << final_residual_norm << "\n";
+        ss << "  - Норма ошибки ||u-x||: " << std::scientific << final_error_norm << "\n\n";
+        ss << "ПРИМЕЧАНИЯ:\n----------\n";
+        ss << "- Все нормы вычислены как maximum-norm (максимальный модуль элемента)\n";
+        ss << "- Для сравнения с истинным решением используется функция u(x,y) = exp(x^2 - y^2)\n";
+        return ss.str();
     }
 private:
     int last_printed_ = -1;
@@ -398,37 +420,78 @@ struct SolverResults {
     std::string stop_reason;
 };
 
-// File formats are a "next" row: plain, self-describing text for now.
+// Text formats of solver/dirichlet_solver.cpp:255-457: section keywords, line order and number formats
+// (default stream format for the header values, std::scientific for the vectors) as the reference writes
+// them.  loadResults reads each section up to the next keyword instead of assuming n*m entries (the
+// reference's reader cannot re-read its own writer's files, SURVEY section 5: save writes U entries).
 class ResultsIO {
-    static void dump(std::ostream& os, const char* tag, const std::vector<double>& v) {
-        os << "[" << tag << "]\n" << v.size() << "\n" << std::setprecision(17);
-        for (double x : v) os << x << "\n";
+    static void put(std::ostream& os, const char* tag, const std::vector<double>& v) {
+        os << tag << "\n";
+        for (double x : v) os << std::scientific << x << "\n";
+    }
+    static bool get(std::istream& is, const std::string& tag, std::vector<double>& v, std::string& pending) {
+        std::string line = pending;
+        pending.clear();
+        while (line.empty()) if (!std::getline(is, line)) return false;
+        if (line != tag) { pending = line; return false; }
+        v.clear();
+        while (std::getline(is, line)) {
+            if (line.empty()) continue;
+            char* end = nullptr;
+            const double x = std::strtod(line.c_str(), &end);
+            if (end == line.c_str()) { pending = line; break; }        // next section keyword
+            v.push_back(x);
+        }
+        return true;
     }
 public:
     static bool saveResults(const std::string& filename, const SolverResults& r, int n, int m, double a, double b, double c,
                             double d, const std::string& solver_name) {
-        std::ofstream os(filename);
-        if (!os.is_open()) return false;
-        os << "[PARAMETERS]\n" << std::setprecision(17) << "n=" << n << "\nm=" << m << "\na=" << a << "\nb=" << b << "\nc=" << c << "\nd=" << d
-           << "\nsolver=" << solver_name << "\n[CONVERGENCE]\niterations=" << r.iterations << "\nconverged=" << (r.converged ? 1 : 0)
-           << "\nresidual_norm=" << r.residual_norm << "\nerror_norm=" << r.error_norm << "\nstop_reason=" << r.stop_reason << "\n";
-        dump(os, "SOLUTION", r.solution); dump(os, "TRUE_SOLUTION", r.true_solution); dump(os, "RESIDUAL", r.residual);
-        dump(os, "ERROR", r.error); dump(os, "X_COORDS", r.x_coords); dump(os, "Y_COORDS", r.y_coords);
-        return os.good();
+        std::ofstream file(filename);
+        if (!file) return false;
+        file << "PARAMETERS\n" << n << " " << m << "\n" << a << " " << b << " " << c << " " << d << "\n" << solver_name << "\n";
+        file << "CONVERGENCE\n" << r.iterations << "\n" << (r.converged ? "1" : "0") << "\n" << r.stop_reason << "\n";
+        file << std::scientific << r.residual_norm << " " << r.error_norm << "\n";
+        put(file, "SOLUTION", r.solution); put(file, "TRUE_SOLUTION", r.true_solution); put(file, "RESIDUAL", r.residual);
+        put(file, "ERROR", r.error); put(file, "X_COORDS", r.x_coords); put(file, "Y_COORDS", r.y_coords);
+        return true;
+    }
+    static bool loadResults(const std::string& filename, SolverResults& r, int& n, int& m, double& a, double& b, double& c,
+                            double& d, std::string& solver_name) {
+        std::ifstream file(filename);
+        if (!file) return false;
+        std::string line;
+        if (!std::getline(file, line) || line != "PARAMETERS") return false;
+        file >> n >> m >> a >> b >> c >> d;
+        file.ignore();
+        std::getline(file, solver_name);
+        if (!std::getline(file, line) || line != "CONVERGENCE") return false;
+        int conv = 0;
+        file >> r.iterations >> conv;
+        r.converged = conv == 1;
+        file.ignore();
+        std::getline(file, r.stop_reason);
+        file >> r.residual_norm >> r.error_norm;
+        file.ignore();
+        std::string pending;
+        if (!get(file, "SOLUTION", r.solution, pending) || !get(file, "TRUE_SOLUTION", r.true_solution, pending) ||
+            !get(file, "RESIDUAL", r.residual, pending) || !get(file, "ERROR", r.error, pending)) return false;
+        get(file, "X_COORDS", r.x_coords, pending);                     // optional in the reference's reader too
+        get(file, "Y_COORDS", r.y_coords, pending);
+        return true;
     }
     static bool saveMatrixAndRhs(const std::string& filename, const KokkosCrsMatrix& A, const KokkosVector& b, int n, int m) {
-        std::ofstream os(filename);
-        if (!os.is_open()) return false;
+        std::ofstream file(filename);
+        if (!file) return false;
         A.materialize();
-        os << "n=" << n << " m=" << m << " rows=" << A.numRows() << " nnz=" << A.nnz() << "\n[ROW_MAP]\n";
-        for (auto v : A.graph.row_map) os << v << "\n";
-        os << "[ENTRIES]\n";
-        for (auto v : A.graph.entries) os << v << "\n";
-        os << "[VALUES]\n" << std::setprecision(17);
-        for (auto v : A.values) os << v << "\n";
-        os << "[RHS]\n";
-        for (size_t i = 0; i < b.extent(0); ++i) os << b(i) << "\n";
-        return os.good();
+        const long long num_rows = A.numRows(), nnz = A.nnz();
+        file << "MATRIX_INFO\n" << n << " " << m << "\n" << num_rows << " " << nnz << "\nMATRIX\n";
+        for (long long i = 0; i <= num_rows; ++i) file << A.graph.row_map[(size_t)i] << "\n";
+        for (long long i = 0; i < nnz; ++i) file << A.graph.entries[(size_t)i] << "\n";
+        for (long long i = 0; i < nnz; ++i) file << std::scientific << A.values[(size_t)i] << "\n";
+        file << "RHS\n";
+        for (long long i = 0; i < num_rows; ++i) file << std::scientific << b((size_t)i) << "\n";
+        return true;
     }
     static bool saveSolutionFor3D(const std::string& filename, const std::vector<std::vector<double>>& solution,
                                   double a_bound, double b_bound, double c_bound, double d_bound) {

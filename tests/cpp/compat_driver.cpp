@@ -49,8 +49,17 @@ int main(int argc, char** argv) {
         std::printf("\"ds_iterations\": %d, \"ds_converged\": %d, \"ds_residual_norm\": %.17g, \"ds_error_norm\": %.17g, \"ds_completions\": %d,\n",
                     r.iterations, r.converged ? 1 : 0, r.residual_norm, r.error_norm, completions);
         jvec("ds_solution", r.solution); jvec("ds_residual", r.residual); jvec("ds_error", r.error);
-        const bool saved = ds.saveResultsToFile("/tmp/mi355cg_compat_results.txt") && ds.saveMatrixAndRhsToFile("/tmp/mi355cg_compat_matrix.txt");
-        std::printf("\"ds_saved\": %d, \"ds_method\": \"%s\",\n", saved ? 1 : 0, ds.getMethodName().empty() ? "" : "set");
+        const std::string dir = argc > 3 ? argv[3] : "/tmp";
+        const bool saved = ds.saveResultsToFile(dir + "/results.txt") && ds.saveMatrixAndRhsToFile(dir + "/matrix.txt");
+        { std::ofstream rep(dir + "/report.txt"); rep << ds.generateReport(); }
+        SolverResults back; int n2 = 0, m2 = 0; double a2, b2, c2, d2; std::string name2;
+        const bool loaded = ResultsIO::loadResults(dir + "/results.txt", back, n2, m2, a2, b2, c2, d2, name2);
+        const bool same = loaded && n2 == N && m2 == N && back.iterations == r.iterations && back.converged == r.converged &&
+                          back.stop_reason == r.stop_reason && back.solution.size() == r.solution.size() &&
+                          back.y_coords.size() == r.y_coords.size() && name2 == ds.getMethodName();
+        std::printf("\"ds_saved\": %d, \"ds_roundtrip\": %d, \"ds_method\": \"%s\",\n", saved ? 1 : 0, same ? 1 : 0, ds.getMethodName().empty() ? "" : "set");
+        jvec("ds_true_solution", r.true_solution); jvec("ds_x_coords", r.x_coords); jvec("ds_y_coords", r.y_coords);
+        std::printf("\"ds_stop_reason\": \"%s\",\n", r.stop_reason.c_str());
     }
     {   // matrix-free pair
         MatrixFreeSystem sys(N, N, 1.0, 2.0, 1.0, 2.0);

@@ -35,7 +35,9 @@ def test_compat_headers_compile_warning_free():
 def test_cpp_dropin_matches_oracle(N):
     from oracle.oracle import OracleGrid
     exe = build_driver()
-    out = subprocess.run([exe, str(N), "10000"], capture_output=True, text=True, timeout=300)
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="mi355cg_compat_")
+    out = subprocess.run([exe, str(N), "10000", tmp], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     j = json.loads(out.stdout)
     og = OracleGrid(N, N)
@@ -52,7 +54,7 @@ def test_cpp_dropin_matches_oracle(N):
     assert j["node0"] == [xs[0], ys[0]]
     # DirichletSolver flow (error criterion off by default)
     ref = og.msg_solve(eps_precision=1e-8, eps_residual=1e-8, eps_exact_error=-1.0)
-    assert (j["ds_iterations"], bool(j["ds_converged"]), j["ds_completions"], j["ds_saved"]) == (ref.iterations, True, 1, 1)
+    assert (j["ds_iterations"], bool(j["ds_converged"]), j["ds_completions"], j["ds_saved"], j["ds_roundtrip"]) == (ref.iterations, True, 1, 1, 1)
     sol = np.array(j["ds_solution"])
     assert np.array_equal(np.array(j["ds_residual"]), og.apply(sol) - og.rhs())
     assert np.array_equal(np.array(j["ds_error"]), sol - og.true_solution())
@@ -62,7 +64,25 @@ def test_cpp_dropin_matches_oracle(N):
     assert (j["mf_iterations"], j["mf_completed_ok"]) == (mf.iterations, 1)
     assert np.array_equal(np.array(j["mf_apply_ones"]), og.apply(np.ones(og.size)))
     assert np.abs(np.array(j["mf_x"]) - mf.x).max() <= 1e-9 * np.abs(mf.x).max()
-    # CSR export written by saveMatrixAndRhsToFile has the reference's entry order
-    txt = open("/tmp/mi355cg_compat_matrix.txt").read().split("[ENTRIES]")[1].split("[VALUES]")
-    entries = np.array(txt[0].split(), dtype=int)
-    assert np.array_equal(entries, og.csr()[1])
+    # ---- file formats, restated here from solver/dirichlet_solver.cpp:255-457 and
+    # solver/msg_solver.cpp:261-304: C++ default stream format = %g, std::scientific = %e
+    sci = lambda v: "%e" % v
+    name = "Метод серединных градиентов"
+    exp = ["PARAMETERS", f"{N} {N}", "1 2 1 2", name, "CONVERGENCE", str(j["ds_iterations"]), "1", j["ds_stop_reason"],
+           f"{sci(j['ds_residual_norm'])} {sci(j['ds_error_norm'])}"]
+    for tag, key in (("SOLUTION", "ds_solution"), ("TRUE_SOLUTION", "ds_true_solution"), ("RESIDUAL", "ds_residual"),
+                     ("ERROR", "ds_error"), ("X_COORDS", "ds_x_coords"), ("Y_COORDS", "ds_y_coords")):
+        exp.append(tag)
+        exp.extend(sci(v) for v in j[key])
+    assert open(os.path.join(tmp, "results.txt"), encoding="utf-8").read() == "\n".join(exp) + "\n"
+    row_map, entries, values = og.csr()
+    expm = ["MATRIX_INFO", f"{N} {N}", f"{og.size} {len(values)}", "MATRIX"] + [str(v) for v in row_map] + \
+           [str(v) for v in entries] + [sci(v) for v in values] + ["RHS"] + [sci(v) for v in og.rhs()]
+    assert open(os.path.join(tmp, "matrix.txt")).read() == "\n".join(expm) + "\n"
+    rep = open(os.path.join(tmp, "report.txt"), encoding="utf-8").read()
+    assert rep.startswith("ОТЧЕТ О РЕШЕНИИ ЗАДАЧИ ДИРИХЛЕ\n===========================\n\nПАРАМЕТРЫ ЗАДАЧИ:\n")
+    assert f"Размер сетки: {N}x{N} внутренних узлов\nОбласть: [1, 2] x [1, 2]\nШаг по x: {'%g' % (1.0 / (N + 1))}\n" in rep
+    assert f"Общее количество неизвестных: {N * N}\n" in rep and f"Название метода: {name}\nМаксимальное число итераций: 10000\n" in rep
+    assert f"Выполнено итераций: {j['ds_iterations']}\nСходимость: Да\nПричина остановки: {j['ds_stop_reason']}\n" in rep
+    assert f"  - Норма невязки ||Ax-b||: {sci(j['ds_residual_norm'])}\n  - Норма ошибки ||u-x||: {sci(j['ds_error_norm'])}\n" in rep
+    assert rep.endswith("- Для сравнения с истинным решением используется функция u(x,y) = exp(x^2 - y^2)\n")

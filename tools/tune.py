@@ -16,7 +16,7 @@ ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 U = (N // 2 - 1) * (3 * N // 2 - 1)
 
 
-def run(env):
+def measure(env):
     for k, v in env.items():
         os.environ[k] = str(v)
     s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
@@ -28,15 +28,30 @@ def run(env):
     h.set_profiling(True); h.solve(p); h.set_profiling(False)
     ts, tu = h.kernel_time(0)[0], h.kernel_time(1)[0]
     lay = h.layout()
-    print(f"{env} its/s={ITERS/dt:8.1f} GB/s(88B)={88*U*ITERS/dt/1e9:7.1f} stencil={ts*1e3:7.1f}us ({(32 if os.environ.get('MI355CG_XFUSE')=='0' else 48)*U/ts/1e6:6.0f} GB/s) "
-          f"update={tu*1e3:7.1f}us ({(48 if os.environ.get('MI355CG_XFUSE')=='0' else 24)*U/tu/1e6:6.0f} GB/s) grid={lay['grid_stencil']}/{lay['grid_update']} ty={lay['rows_per_item']}", flush=True)
     h.close()
+    return ITERS / dt, ts, tu, lay
+
+
+def run(env):
+    its, ts, tu, lay = measure(env)
+    xf = os.environ.get('MI355CG_XFUSE', '1') != '0'
+    ws, wu = (48, 24) if xf else (32, 48)
+    print(f"{env} its/s={its:8.1f} GB/s(88B)={88*U*its/1e9:7.1f} stencil={ts*1e3:7.1f}us ({ws*U/ts/1e6:6.0f} GB/s) "
+          f"update={tu*1e3:7.1f}us ({wu*U/tu/1e6:6.0f} GB/s) grid={lay['grid_stencil']}/{lay['grid_update']} ty={lay['rows_per_item']}", flush=True)
+
+
+def ab(configs, rounds=5):
+    """Interleaved rounds in one process (the boxes drift by several % within seconds): median and best per config."""
+    res = {i: [] for i in range(len(configs))}
+    for _ in range(rounds):
+        for i, env in enumerate(configs):
+            res[i].append(measure(env)[0])
+    for i, env in enumerate(configs):
+        v = sorted(res[i])
+        print(f"{env} median {v[len(v)//2]:8.1f} it/s   best {v[-1]:8.1f}   worst {v[0]:8.1f}", flush=True)
 
 
 if __name__ == "__main__":
-    z = {"MI355CG_XFUSE": 1, "MI355CG_UPDATE_BLOCKS": 512}
-    run(z); run(z)
-    for ub in (256, 384, 768, 1024, 2048):
-        run({**z, "MI355CG_UPDATE_BLOCKS": ub})
-    run({**z, "MI355CG_XFUSE": 0}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_UPDATE_BLOCKS": 1024}); run({**z, "MI355CG_XFUSE": 0, "MI355CG_UPDATE_BLOCKS": 256})
-    run(z)
+    base = {"MI355CG_XFUSE": 1, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_UPDATE_BLOCKS": 512, "MI355CG_UPDATE_DESC": 1}
+    ab([base, {**base, "MI355CG_UPDATE_BLOCKS": 256}, {**base, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 3072},
+        {**base, "MI355CG_UPDATE_DESC": 0}, {**base, "MI355CG_XFUSE": 0}], rounds=7)
