@@ -335,3 +335,74 @@ def test_x_update_folded_into_stencil_is_bit_identical(isa, N, max_it, sync, mon
         out.append((x, sol.getIterations(), s._handle.recursive_residual(), sol.last_results.r_norm2))
     assert out[0][1] == out[1][1]
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+
+
+def test_caller_supplied_rhs_and_repeated_solves(isa, oracle):
+    """Solver(a, b, ...) with a b that is not the grid's own (solver.hpp:33-39), twice on one handle."""
+    N = 48
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    rng = np.random.default_rng(3)
+    for trial in range(2):
+        b = rng.standard_normal(s.size()) * 10.0 ** trial
+        ref = og.mf_solve(b=b, eps=1e-9, max_iterations=10 ** 5)
+        sol = isa.MatrixFreeSolver(s, b, 1e-9, 10 ** 5)
+        x = sol.solve()
+        assert sol.getIterations() == ref.iterations
+        assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+        refm = og.msg_solve(b=b, eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
+        m = isa.MSGSolver(s, b, 1e-9, 10000)
+        m.setExactErrorEps(-1.0)
+        xm = m.solve(s.get_true_solution_vector())
+        assert (m.getIterations(), int(m.getStopReason())) == (refm.iterations, refm.stop_reason)
+        assert np.abs(xm - refm.x).max() <= 1e-9 * np.abs(refm.x).max()
+        assert m.getFinalErrorNorm() == pytest.approx(refm.final_error_norm, rel=1e-9)   # error vs u although b is foreign
+    assert np.array_equal(s.apply(b), og.apply(b))               # the handle still applies the operator bit-exactly
+
+
+def test_zero_rhs_matches_the_reference_breakdown_behaviour(isa, oracle):
+    """b = 0: MatrixFreeSolver never enters its loop; MSGSolver divides 0/0 in its first iteration
+    (msg_solver.cpp:102, unchecked) and then stops on the precision test because std::max ignores NaN."""
+    N = 16
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    b = np.zeros(s.size())
+    sol = isa.MatrixFreeSolver(s, b, 1e-8, 100)
+    x = sol.solve()
+    ref = og.mf_solve(b=b, eps=1e-8, max_iterations=100)
+    assert (sol.getIterations(), bool(sol.last_results.converged)) == (ref.iterations, ref.converged) == (0, True)
+    assert np.array_equal(x, ref.x)
+    m = isa.MSGSolver(s, b, 1e-6, 100)
+    xm = m.solve(s.get_true_solution_vector())
+    refm = og.msg_solve(b=b)
+    assert (m.getIterations(), int(m.getStopReason()), m.hasConverged()) == (refm.iterations, refm.stop_reason, refm.converged)
+    assert np.array_equal(np.isnan(xm), np.isnan(refm.x))
+
+
+def test_apply_device_pointer_entry(isa, oracle):
+    """mi355cg_apply_device: packed vectors already resident in HBM (torch tensors as plain pointers)."""
+    import ctypes as C
+    import torch
+    from iterative_solvers_amd import _capi
+    N = 130
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    x = torch.rand(s.size(), dtype=torch.float64, device="cuda") * 2 - 1
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    _capi.check(_capi.load().mi355cg_apply_device(s._handle._h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())))
+    assert np.array_equal(y.cpu().numpy(), og.apply(x.cpu().numpy()))
+
+
+def test_kernel_timing_hooks(isa):
+    s = isa.MatrixFreeSystem(256, 256, 1.0, 2.0, 1.0, 2.0)
+    h = s._handle
+    p = isa.default_params(isa.RULE_REL_2NORM)
+    p.max_iterations, p.fixed_iterations = 50, 1
+    h.set_profiling(True)
+    h.solve(p)
+    h.set_profiling(False)
+    (ms0, n0), (ms1, n1) = h.kernel_time(0), h.kernel_time(1)
+    assert n0 == n1 == 50 and 0 < ms0 < 5 and 0 < ms1 < 5
+    lay = h.layout()
+    assert lay["pitch_upper"] % 32 == 0 and lay["pitch_bottom"] % 32 == 0 and lay["padded_len"] >= s.size()
