@@ -86,3 +86,36 @@ def test_cpp_dropin_matches_oracle(N):
     assert f"Выполнено итераций: {j['ds_iterations']}\nСходимость: Да\nПричина остановки: {j['ds_stop_reason']}\n" in rep
     assert f"  - Норма невязки ||Ax-b||: {sci(j['ds_residual_norm'])}\n  - Норма ошибки ||u-x||: {sci(j['ds_error_norm'])}\n" in rep
     assert rep.endswith("- Для сравнения с истинным решением используется функция u(x,y) = exp(x^2 - y^2)\n")
+
+
+def _build_cli():
+    from iterative_solvers_amd import build as b
+    b.build()
+    src = os.path.join(ROOT, "iterative_solvers_amd", "cli", "solver_main.cpp")
+    exe = os.path.join(ROOT, "iterative_solvers_amd", "cli", "solver_cli")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I",
+                               os.path.join(ROOT, "iterative_solvers_amd", "compat"), src, "-L",
+                               os.path.join(ROOT, "iterative_solvers_amd"), "-lmi355cg",
+                               "-Wl,-rpath," + os.path.join(ROOT, "iterative_solvers_amd"), "-o", exe])
+    return exe
+
+
+def test_console_driver_compiles():
+    assert os.path.exists(_build_cli())
+
+
+@pytest.mark.gpu
+def test_console_driver_config1_plumbing():
+    """BASELINE config 1: 256 x 256 through the console flow of solver/main.cpp (stdin prompts, defaults
+    eps 1e-9 / 2 iterations), then the same grid converged with flags."""
+    exe = _build_cli()
+    out = subprocess.run([exe], input="256 256\n", capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Создание сетки размером 256x256 для области [1,2] x [1,2]" in out.stdout
+    assert "Итераций: 2\n" in out.stdout and "Неизвестных: 48641, итераций: 2" in out.stdout
+    out = subprocess.run([exe, "--n", "256", "--eps", "1e-8", "--max-iter", "100000", "--rule", "rel2"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "итераций: 701," in out.stdout            # the reference's own count (SURVEY section 6)
+    out = subprocess.run([exe, "--n", "7"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "rejected" in out.stderr
