@@ -94,6 +94,11 @@ struct mi355cg_ctx {
     int cur = 0;                        // p[cur] holds the current direction after the last stencil
     int nA_dist = 0;                    // slab mode: stencil partial slots written by the last stencil phase
 
+    // hipGraph cache for launch-bound (small) grids: one instantiated graph per distinct chunk shape of a solve
+    struct ChunkGraph { int m, cur; std::vector<char> flags; hipGraphExec_t exec; };
+    std::vector<ChunkGraph> graphs;
+    int use_graph = -1;                 // env MI355CG_GRAPH: -1 auto (small grids), 0 off, 1 on
+
     bool profiling = false;
     EventPool events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[2];
@@ -188,6 +193,7 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     c->nt_mask = env_int("MI355CG_NT", 0);
     c->xfuse = env_int("MI355CG_XFUSE", 1);
     c->xdepth = env_int("MI355CG_XDEPTH", 2);
+    c->use_graph = env_int("MI355CG_GRAPH", -1);
 }
 
 PackGeom pack_geom(const mi355cg_ctx* c) {
@@ -345,6 +351,11 @@ int ensure_u_on_device(mi355cg_ctx* c) {
     if (int rc = upload_packed<double>(c, c->u_h.data(), c->u)) return rc;
     c->have_u_dev = true;
     return MI355CG_OK;
+}
+
+void clear_graphs(mi355cg_ctx* c) {
+    for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
 }
 
 void prof_begin(mi355cg_ctx* c, int k, hipEvent_t* e0) {
@@ -592,6 +603,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (c->summary_h) hipHostFree(c->summary_h);
     if (c->hist_h) hipHostFree(c->hist_h);
     if (c->partR_h) hipHostFree(c->partR_h);
+    clear_graphs(c);
     c->events.destroy();
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -704,29 +716,60 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     const int every = prm->callback_every;
     int it_done = 0;
     bool interrupted = false;
+    clear_graphs(c);                                             // kernel arguments embed this solve's parameters
+    const bool graph_ok = !c->profiling && !diag &&
+                          (c->use_graph == 1 || (c->use_graph < 0 && c->g.own_len < (4LL << 20) && prm->max_iterations >= 4 * sync_every));
     while (!c->summary_h->done) {
         if (stop_flag && *stop_flag) { interrupted = true; break; }            // msg_solver.cpp:82-87
         int m = std::min(sync_every, prm->max_iterations - it_done);
         if (msg && every > 0) m = std::min(m, every - it_done % every);        // land on the callback iterations
         if (m <= 0) m = 1;                                                    // lets the kernels record ITERATIONS
-        for (int k = 0; k < m; ++k) {
-            hipEvent_t e0 = nullptr;
-            prof_begin(c, 0, &e0);
-            launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, whole_slab(c), own_partB(c), c->x);
-            c->cur ^= 1;
-            prof_end(c, 0, e0);
-            prof_begin(c, 1, &e0);
-            IterCfg ucfg = cfg;
-            ucfg.has_u = cfg.has_u && need_u(it_done + k + 1);      // skip the u stream when nothing reads the error norm
-            launch_update<double, 2>(c, ucfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c));
-            prof_end(c, 1, e0);
-            if (diag) {
-                // MatrixFreeSolver's per-iteration report: second apply for the TRUE residual
-                // (matrix_free_system.cpp:457-468).  One iteration per poll in this mode.
-                launch_apply<double, 2>(c, c->x, c->p[c->cur ^ 1]);            // scratch: the inactive direction buffer
-                hipLaunchKernelGGL((k_resid2<double>), dim3(1024), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->p[c->cur ^ 1], c->partR);
-                HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * 1024, hipMemcpyDeviceToHost, c->stream));
+        auto enqueue_chunk = [&]() -> int {
+            for (int k = 0; k < m; ++k) {
+                hipEvent_t e0 = nullptr;
+                prof_begin(c, 0, &e0);
+                launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, whole_slab(c), own_partB(c), c->x);
+                c->cur ^= 1;
+                prof_end(c, 0, e0);
+                prof_begin(c, 1, &e0);
+                IterCfg ucfg = cfg;
+                ucfg.has_u = cfg.has_u && need_u(it_done + k + 1);      // skip the u stream when nothing reads the error norm
+                launch_update<double, 2>(c, ucfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c));
+                prof_end(c, 1, e0);
+                if (diag) {
+                    // MatrixFreeSolver's per-iteration report: second apply for the TRUE residual
+                    // (matrix_free_system.cpp:457-468).  One iteration per poll in this mode.
+                    launch_apply<double, 2>(c, c->x, c->p[c->cur ^ 1]);            // scratch: the inactive direction buffer
+                    hipLaunchKernelGGL((k_resid2<double>), dim3(1024), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->p[c->cur ^ 1], c->partR);
+                    HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * 1024, hipMemcpyDeviceToHost, c->stream));
+                }
             }
+            return MI355CG_OK;
+        };
+        if (graph_ok && m >= 8 && (m % 2) == 0) {
+            // Launch-bound grids: replay the chunk as one hipGraph.  The chunk's kernel arguments depend only on
+            // (m, direction-buffer parity, which iterations read u), so equal shapes share an instantiated graph.
+            std::vector<char> flags(m);
+            for (int k = 0; k < m; ++k) flags[k] = cfg.has_u && need_u(it_done + k + 1);
+            mi355cg_ctx::ChunkGraph* hit = nullptr;
+            for (auto& g : c->graphs) if (g.m == m && g.cur == c->cur && g.flags == flags) hit = &g;
+            if (!hit) {
+                hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+                const int cur0 = c->cur;
+                HIPCK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                const int rc = enqueue_chunk();
+                const hipError_t e1 = hipStreamEndCapture(c->stream, &graph);
+                c->cur = cur0;                                   // the capture only recorded; nothing ran
+                if (rc) return rc;
+                HIPCK(e1);
+                HIPCK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                HIPCK(hipGraphDestroy(graph));
+                c->graphs.push_back({m, cur0, flags, exec});
+                hit = &c->graphs.back();
+            }
+            HIPCK(hipGraphLaunch(hit->exec, c->stream));          // m is even: the parity of c->cur is unchanged
+        } else {
+            if (int rc = enqueue_chunk()) return rc;
         }
         HIPCK(hipGetLastError());
         if (int rc = poll()) return rc;
