@@ -148,6 +148,7 @@ int  mi355cg_owned_range(mi355cg_handle h, long long *packed_begin, long long *p
 int  mi355cg_dist_begin(mi355cg_handle h, const mi355cg_params *params, void *stream);
 int  mi355cg_dist_reduce(mi355cg_handle h, int which /*0 stencil, 1 update*/, int with_rows, void *stream);
 int  mi355cg_dist_sums_ptr(mi355cg_handle h, int which, void **dev_ptr, int *count /*record width*/);
+int  mi355cg_dist_record_layout(mi355cg_handle h, int *header, int *row_slot, int *width);   /* doubles */
 int  mi355cg_dist_scatter_ghosts(mi355cg_handle h, int vector /*0 r, 1 current direction*/,
                                  const double *gathered_records, int nranks, int rank, void *stream);
 int  mi355cg_dist_stencil(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride,

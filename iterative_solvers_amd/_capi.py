@@ -21,7 +21,7 @@ EXPORTS = [
     "mi355cg_get_solution", "mi355cg_get_recursive_residual", "mi355cg_get_true_residual",
     "mi355cg_set_profiling", "mi355cg_get_kernel_time", "mi355cg_get_layout",
     "mi355cg_slab_rows", "mi355cg_create_slab", "mi355cg_owned_range", "mi355cg_dist_begin",
-    "mi355cg_dist_reduce", "mi355cg_dist_sums_ptr", "mi355cg_dist_scatter_ghosts", "mi355cg_dist_stencil", "mi355cg_dist_flip",
+    "mi355cg_dist_reduce", "mi355cg_dist_sums_ptr", "mi355cg_dist_record_layout", "mi355cg_dist_scatter_ghosts", "mi355cg_dist_stencil", "mi355cg_dist_flip",
     "mi355cg_dist_update", "mi355cg_dist_check", "mi355cg_dist_summary", "mi355cg_dist_finish", "mi355cg_dist_history",
     "mi355cg_dist_halo", "mi355cg_dist_halo_recv_counts",
 ]
@@ -65,8 +65,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
-    if _build.needs_build():
+    path = os.environ.get("MI355CG_LIB") or _build.LIB_PATH        # MI355CG_LIB: A/B an alternative build of the same ABI
+    if path == _build.LIB_PATH and _build.needs_build():
         try:
             _build.build()
         except Exception as e:  # pre-built .so shipped to a box without hipcc is fine
@@ -100,6 +100,7 @@ def load():
     L.mi355cg_dist_begin.argtypes = [H, C.POINTER(Params), C.c_void_p]
     L.mi355cg_dist_reduce.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_sums_ptr.argtypes = [H, C.c_int, VPP, IP]
+    L.mi355cg_dist_record_layout.argtypes = [H, IP, IP, IP]
     L.mi355cg_dist_scatter_ghosts.argtypes = [H, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_stencil.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_flip.argtypes = [H]

@@ -74,8 +74,35 @@ struct RuleParams {
 };
 
 // partial-sum fields, field-major: part[field * stride + block]
-enum { FA_PAP = 0, FA_RZ = 1, FA_COUNT = 2 };
-enum { FB_RR = 0, FB_RMAX = 1, FB_DMAX = 2, FB_EMAX = 3, FB_D2 = 4, FB_E2 = 5, FB_COUNT = 6 };
+// Sums are carried as double-double pairs (hi at the field, lo at field + *_LO): see dd below.
+enum { FA_PAP = 0, FA_RZ = 1, FA_LO = 2, FA_COUNT = 4 };
+enum { FB_RR = 0, FB_D2 = 1, FB_E2 = 2, FB_LO = 3, FB_RMAX = 6, FB_DMAX = 7, FB_EMAX = 8, FB_COUNT = 9 };
+constexpr int kNumSumsA = 2, kNumSumsB = 3;          // sum fields come first, then their lo words, then the max fields
+
+// ---- double-double accumulation of the inner products ------------------------------------------------
+// Every inner product is accumulated as an unevaluated pair hi + lo (Knuth TwoSum, FMA TwoProduct): the
+// result carries ~100 significant bits, so after the final rounding to double it no longer depends on the
+// order in which lanes, waves, blocks or GPUs were combined (two orders can differ only if the exact sum
+// sits within ~1e-30 of a rounding boundary).  That is what makes 1-, 2-, 4- and 8-GPU runs take bit-identical
+// steps.  It costs VALU work only -- the kernels are an order of magnitude below the VALU roof.
+struct dd { double hi, lo; };
+__device__ inline dd dd_zero() { return dd{0.0, 0.0}; }
+__device__ inline dd two_sum(double a, double b) { const double s = a + b, bb = s - a; return dd{s, (a - (s - bb)) + (b - bb)}; }
+__device__ inline dd dd_add(dd a, dd b) {
+    const dd s = two_sum(a.hi, b.hi);
+    const double lo = s.lo + (a.lo + b.lo);
+    const double hi = s.hi + lo;
+    return dd{hi, lo - (hi - s.hi)};
+}
+__device__ inline void dd_acc_prod(dd& acc, double a, double b) {          // acc += a*b, product exact
+#ifdef MI355CG_PLAIN_DOT                                                   // A/B build only: plain double accumulation
+    acc.hi += a * b;
+#else
+    const double p = a * b;
+    acc = dd_add(acc, dd{p, fma(a, b, -p)});
+#endif
+}
+__device__ inline double dd_value(dd a) { return a.hi + a.lo; }
 
 // ---- block-level deterministic reductions ----------------------------------------------------------
 __device__ inline double wave_sum(double v) {
@@ -109,6 +136,30 @@ __device__ inline double reduce_parts(const double* __restrict__ part, int n, in
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += kBlock) v = IS_MAX ? fmax(v, part[(long long)i * es]) : v + part[(long long)i * es];
     return block_reduce<IS_MAX>(v, lds);
+}
+
+__device__ inline dd wave_sum_dd(dd v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = dd_add(v, dd{__shfl_down(v.hi, o, kWave), __shfl_down(v.lo, o, kWave)});
+    return v;
+}
+// lds: >= 2*kWaves doubles
+__device__ inline dd block_reduce_dd(dd v, double* lds) {
+    v = wave_sum_dd(v);
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    __syncthreads();
+    if (lane == 0) { lds[2 * w] = v.hi; lds[2 * w + 1] = v.lo; }
+    __syncthreads();
+    dd t{lds[0], lds[1]};
+#pragma unroll
+    for (int k = 1; k < kWaves; ++k) t = dd_add(t, dd{lds[2 * k], lds[2 * k + 1]});
+    return t;
+}
+// partial pairs: hi words at part_hi[i*es], lo words at part_lo[i*es]
+__device__ inline dd reduce_parts_dd(const double* __restrict__ part_hi, const double* __restrict__ part_lo, int n, int es, double* lds) {
+    dd v = dd_zero();
+    for (int i = threadIdx.x; i < n; i += kBlock) v = dd_add(v, dd{part_hi[(long long)i * es], part_lo[(long long)i * es]});
+    return block_reduce_dd(v, lds);
 }
 
 // ---- the decision taken after every update: convergence tests, beta ------------------------------
@@ -154,7 +205,7 @@ __device__ inline void write_state_after_decision(CgState* out, HistEntry* hist,
 // Reduce the update kernel's partials (only the fields the rule needs) and decide.
 __device__ inline Decision reduce_and_decide(const CgState& s, const RuleParams& rp, const double* partB,
                                              int nB, int strideB, int esB, int want_diag, double* lds) {
-    const double rr = reduce_parts<false>(partB + FB_RR * strideB, nB, esB, lds);
+    const double rr = dd_value(reduce_parts_dd(partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, esB, lds));
     double rmax = 0, dmax = 0, emax = 0, d2 = 0, e2 = 0;
     if (rp.rule == 0 || want_diag) {
         rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, esB, lds);
@@ -162,8 +213,8 @@ __device__ inline Decision reduce_and_decide(const CgState& s, const RuleParams&
         if (rp.use_u) emax = reduce_parts<true>(partB + FB_EMAX * strideB, nB, esB, lds);
     }
     if (want_diag) {
-        d2 = reduce_parts<false>(partB + FB_D2 * strideB, nB, esB, lds);
-        if (rp.use_u) e2 = reduce_parts<false>(partB + FB_E2 * strideB, nB, esB, lds);
+        d2 = dd_value(reduce_parts_dd(partB + FB_D2 * strideB, partB + (FB_D2 + FB_LO) * strideB, nB, esB, lds));
+        if (rp.use_u) e2 = dd_value(reduce_parts_dd(partB + FB_E2 * strideB, partB + (FB_E2 + FB_LO) * strideB, nB, esB, lds));
     }
     return decide_after_update(s, rp, rr, rmax, dmax, emax, d2, e2);
 }
@@ -226,7 +277,7 @@ __device__ inline Item decode_item(const WorkList& wl, int item) {
 template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool DESC, bool XUPD = false>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     typedef typename VecOf<T, VEC>::type vec_t;
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     const Geom& g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR item decode
@@ -243,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     }
 
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
-    double acc_pap = 0.0, acc_rz = 0.0;
+    dd acc_pap = dd_zero(), acc_rz = dd_zero();
     constexpr int DIR = DESC ? -1 : 1;
 
     struct Raw { vec_t r, p, x; T re, pe; };
@@ -331,8 +382,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                         v = v + cyk * bot[j];
                         const int xj = x + j;
                         out[j] = (xj >= xint0 && xj <= g.N - 1) ? v : (T)0;
-                        acc_pap += (double)c * (double)out[j];
-                        if (MSG) acc_rz += (double)r_c[j] * (double)c;
+                        dd_acc_prod(acc_pap, (double)c, (double)out[j]);
+                        if (MSG) dd_acc_prod(acc_rz, (double)r_c[j], (double)c);
                     }
                     {   // branch-free stores: lanes outside the stored columns write the trash block
                         const bool sv = xin && x >= cmin;
@@ -353,12 +404,13 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         }
     }
 
-    const double tp = block_reduce<false>(acc_pap, lds);
-    double tz = 0.0;
-    if (MSG) tz = block_reduce<false>(acc_rz, lds);
+    const dd tp = block_reduce_dd(acc_pap, lds);
+    dd tz = dd_zero();
+    if (MSG) tz = block_reduce_dd(acc_rz, lds);
     if (threadIdx.x == 0 && a.partA) {
-        a.partA[FA_PAP * a.strideA + a.slotA + blockIdx.x] = tp;
-        a.partA[FA_RZ * a.strideA + a.slotA + blockIdx.x] = tz;
+        const int b = a.slotA + blockIdx.x, st = a.strideA;
+        a.partA[FA_PAP * st + b] = tp.hi; a.partA[(FA_PAP + FA_LO) * st + b] = tp.lo;
+        a.partA[FA_RZ * st + b] = tz.hi;  a.partA[(FA_RZ + FA_LO) * st + b] = tz.lo;
     }
 }
 
@@ -380,7 +432,7 @@ struct UpdateArgs {
 template <typename T, int VEC, bool HAS_U>
 __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     typedef typename VecOf<T, VEC>::type vec_t;
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     CgState s;
     double alpha_d = 0.0, rz = 0.0;
     if (a.init) {
@@ -388,9 +440,9 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     } else {
         s = *a.s_in;
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
-        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, a.esA, lds);
+        const double pap = dd_value(reduce_parts_dd(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
         if (a.rule == 0) {
-            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, a.esA, lds);
+            rz = dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
             alpha_d = rz / pap;                       // msg_solver.cpp:102
         } else {
             alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
@@ -398,7 +450,8 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     }
     const T alpha = (T)alpha_d;
 
-    double s_rr = 0, s_rmax = 0, s_dmax = 0, s_emax = 0, s_d2 = 0, s_e2 = 0;
+    dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
+    double s_rmax = 0, s_dmax = 0, s_emax = 0;
     const long long stride = (long long)gridDim.x * kBlock;
     vec_t* __restrict__ X = reinterpret_cast<vec_t*>(a.x);                 // five distinct vectors: no aliasing
     vec_t* __restrict__ R = reinterpret_cast<vec_t*>(a.r);
@@ -415,15 +468,15 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
             xn[j] = x0[j] + alpha * pv[j];            // x = x + alpha*z        msg_solver.cpp:105-107
             rn[j] = r0[j] - alpha * qv[j];            // r = r - alpha*A_z      msg_solver.cpp:110-112
             const double rd = (double)rn[j];
-            s_rr += rd * rd;
+            dd_acc_prod(s_rr, rd, rd);
             s_rmax = fmax(s_rmax, fabs(rd));
-            const double dd = (double)(xn[j] - x0[j]); // diff = x - x_prev     msg_solver.cpp:124-127
-            s_dmax = fmax(s_dmax, fabs(dd));
-            s_d2 += dd * dd;
+            const double dx = (double)(xn[j] - x0[j]); // diff = x - x_prev     msg_solver.cpp:124-127
+            s_dmax = fmax(s_dmax, fabs(dx));
+            dd_acc_prod(s_d2, dx, dx);
             if (HAS_U) {
                 const double ee = (double)(xn[j] - uv[j]);   // error = x - u   msg_solver.cpp:132-136
                 s_emax = fmax(s_emax, fabs(ee));
-                s_e2 += ee * ee;
+                dd_acc_prod(s_e2, ee, ee);
             }
         }
         st_pol(X + i, xn, nt_x); st_pol(R + i, rn, nt_r);
@@ -453,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
                 for (int j = 0; j < VEC; ++j) {
                     rn[j] = r0[k][j] - alpha * qv[k][j];
                     const double rd = (double)rn[j];
-                    s_rr += rd * rd;
+                    dd_acc_prod(s_rr, rd, rd);
                     s_rmax = fmax(s_rmax, fabs(rd));
                 }
                 R[at(i + k * stride)] = rn;
@@ -467,7 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
             for (int j = 0; j < VEC; ++j) {
                 rn[j] = r0[j] - alpha * qv[j];
                 const double rd = (double)rn[j];
-                s_rr += rd * rd;
+                dd_acc_prod(s_rr, rd, rd);
                 s_rmax = fmax(s_rmax, fabs(rd));
             }
             R[j2] = rn;
@@ -485,17 +538,18 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
         if (i < end) body(i);
     }
 
-    const double t_rr = block_reduce<false>(s_rr, lds);
+    const dd t_rr = block_reduce_dd(s_rr, lds);
     const double t_rmax = block_reduce<true>(s_rmax, lds);
     const double t_dmax = block_reduce<true>(s_dmax, lds);
-    const double t_d2 = block_reduce<false>(s_d2, lds);
-    double t_emax = 0, t_e2 = 0;
-    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce<false>(s_e2, lds); }
+    const dd t_d2 = block_reduce_dd(s_d2, lds);
+    double t_emax = 0; dd t_e2 = dd_zero();
+    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce_dd(s_e2, lds); }
     if (threadIdx.x == 0) {
         const int b = blockIdx.x, st = a.strideB;
-        a.partB[FB_RR * st + b] = t_rr;     a.partB[FB_RMAX * st + b] = t_rmax;
-        a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
-        a.partB[FB_D2 * st + b] = t_d2;     a.partB[FB_E2 * st + b] = t_e2;
+        a.partB[FB_RR * st + b] = t_rr.hi; a.partB[(FB_RR + FB_LO) * st + b] = t_rr.lo;
+        a.partB[FB_D2 * st + b] = t_d2.hi; a.partB[(FB_D2 + FB_LO) * st + b] = t_d2.lo;
+        a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
+        a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
         if (blockIdx.x == 0) {
             CgState o = s;
             if (!a.init) { o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz; }
@@ -516,7 +570,7 @@ struct Update2DArgs {
 template <typename T, int VEC, bool HAS_U, int UNROLL, bool DESC>
 __global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
     typedef typename VecOf<T, VEC>::type vec_t;
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     const UpdateArgs<T>& a = aa.u;
     const Geom& g = aa.g;
     const int lane = threadIdx.x & (kWave - 1);
@@ -528,16 +582,17 @@ __global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
     } else {
         s = *a.s_in;
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
-        const double pap = reduce_parts<false>(a.partA + FA_PAP * a.strideA, a.nA, a.esA, lds);
+        const double pap = dd_value(reduce_parts_dd(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
         if (a.rule == 0) {
-            rz = reduce_parts<false>(a.partA + FA_RZ * a.strideA, a.nA, a.esA, lds);
+            rz = dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
             alpha_d = rz / pap;                       // msg_solver.cpp:102
         } else {
             alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
         }
     }
     const T alpha = (T)alpha_d;
-    double s_rr = 0, s_rmax = 0, s_dmax = 0, s_emax = 0, s_d2 = 0, s_e2 = 0;
+    dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
+    double s_rmax = 0, s_dmax = 0, s_emax = 0;
     constexpr int DIR = DESC ? -1 : 1;
 
     for (int item = blockIdx.x * kWaves + wave; item < aa.wl.nitems; item += gridDim.x * kWaves) {
@@ -572,15 +627,15 @@ __global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
                         xn[j] = x0[k][j] + alpha * pv[k][j];        // x = x + alpha*z     msg_solver.cpp:105-107
                         rn[j] = r0[k][j] - alpha * qv[k][j];        // r = r - alpha*A_z   msg_solver.cpp:110-112
                         const double rd = (double)rn[j];
-                        s_rr += rd * rd;
+                        dd_acc_prod(s_rr, rd, rd);
                         s_rmax = fmax(s_rmax, fabs(rd));
-                        const double dd = (double)(xn[j] - x0[k][j]);   // diff = x - x_prev   :124-127
-                        s_dmax = fmax(s_dmax, fabs(dd));
-                        s_d2 += dd * dd;
+                        const double dx = (double)(xn[j] - x0[k][j]);   // diff = x - x_prev   :124-127
+                        s_dmax = fmax(s_dmax, fabs(dx));
+                        dd_acc_prod(s_d2, dx, dx);
                         if (HAS_U) {
                             const double ee = (double)(xn[j] - uv[k][j]);   // error = x - u    :132-136
                             s_emax = fmax(s_emax, fabs(ee));
-                            s_e2 += ee * ee;
+                            dd_acc_prod(s_e2, ee, ee);
                         }
                     }
                     *reinterpret_cast<vec_t*>(a.x + off[k]) = xn;
@@ -590,17 +645,18 @@ __global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
         }
     }
 
-    const double t_rr = block_reduce<false>(s_rr, lds);
+    const dd t_rr = block_reduce_dd(s_rr, lds);
     const double t_rmax = block_reduce<true>(s_rmax, lds);
     const double t_dmax = block_reduce<true>(s_dmax, lds);
-    const double t_d2 = block_reduce<false>(s_d2, lds);
-    double t_emax = 0, t_e2 = 0;
-    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce<false>(s_e2, lds); }
+    const dd t_d2 = block_reduce_dd(s_d2, lds);
+    double t_emax = 0; dd t_e2 = dd_zero();
+    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce_dd(s_e2, lds); }
     if (threadIdx.x == 0) {
         const int b = blockIdx.x, st = a.strideB;
-        a.partB[FB_RR * st + b] = t_rr;     a.partB[FB_RMAX * st + b] = t_rmax;
-        a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
-        a.partB[FB_D2 * st + b] = t_d2;     a.partB[FB_E2 * st + b] = t_e2;
+        a.partB[FB_RR * st + b] = t_rr.hi; a.partB[(FB_RR + FB_LO) * st + b] = t_rr.lo;
+        a.partB[FB_D2 * st + b] = t_d2.hi; a.partB[(FB_D2 + FB_LO) * st + b] = t_d2.lo;
+        a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
+        a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
         if (blockIdx.x == 0) {
             CgState o = s;
             if (!a.init) { o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz; }
@@ -619,22 +675,11 @@ struct CheckArgs {
     int want_diag;
 };
 __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     const CgState s = *a.s_in;
     if (s.done) { if (threadIdx.x == 0) *a.summary = s; return; }
     const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, 1, lds);
     if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, s, d);
-}
-
-// Reduce one kernel's partials into `nf` totals (distributed mode: feeds the all-gather).
-__global__ __launch_bounds__(kBlock) void k_reduce_parts(const double* part, int n, int stride, int nf,
-                                                        unsigned max_mask, double* out) {
-    __shared__ double lds[kWaves];
-    for (int f = 0; f < nf; ++f) {
-        const double v = ((max_mask >> f) & 1u) ? reduce_parts<true>(part + f * stride, n, 1, lds)
-                                                : reduce_parts<false>(part + f * stride, n, 1, lds);
-        if (threadIdx.x == 0) out[f] = v;
-    }
 }
 
 // x += alpha * p over the owned range: the x update still pending when an XUPD loop ends.
@@ -648,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void k_flush_x(long long begin, long long l
 // kernel skipped the u stream because no criterion or callback needed it; msg_solver.cpp:132-139)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_err_maxnorm(long long begin, long long len, const T* x, const T* u, double* part) {
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     const long long stride = (long long)gridDim.x * kBlock;
     double m = 0.0;
     for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride)
@@ -662,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_err_maxnorm(long long begin, long lo
 // over the owned range: forms the fp64 true residual, its norm and the fp32 right-hand side in one pass.
 __global__ __launch_bounds__(kBlock) void k_residual_to_f32(long long total, long long own_begin, long long own_len,
                                                            const double* b, const double* ax, float* rf, double* part) {
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     const long long stride = (long long)gridDim.x * kBlock;
     double s = 0.0;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
@@ -681,16 +726,21 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_f32(long long begin, long
 
 // Slab record = [sums (block 0 reduces the partials) | first owned row | last owned row] in ONE launch.
 struct RecordArgs {
-    const double* part; int n, stride, nf; unsigned max_mask;
+    const double* part; int n, stride;
+    int nsum, lo_off;                                  // sum fields 0..nsum-1 (hi) with lo words at field + lo_off
+    int max_first, nmax;                               // max fields max_first .. max_first+nmax-1
     double* rec; int header, row_slot;                 // rows land at rec + header and rec + header + row_slot
     const double* v; long long off_lo, off_hi; int len_lo, len_hi;   // v == nullptr: sums only
 };
 __global__ __launch_bounds__(kBlock) void k_make_record(const RecordArgs a) {
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     if (blockIdx.x == 0) {
-        for (int f = 0; f < a.nf; ++f) {
-            const double t = ((a.max_mask >> f) & 1u) ? reduce_parts<true>(a.part + f * a.stride, a.n, 1, lds)
-                                                      : reduce_parts<false>(a.part + f * a.stride, a.n, 1, lds);
+        for (int f = 0; f < a.nsum; ++f) {
+            const dd t = reduce_parts_dd(a.part + f * a.stride, a.part + (f + a.lo_off) * a.stride, a.n, 1, lds);
+            if (threadIdx.x == 0) { a.rec[f] = t.hi; a.rec[f + a.lo_off] = t.lo; }
+        }
+        for (int f = a.max_first; f < a.max_first + a.nmax; ++f) {
+            const double t = reduce_parts<true>(a.part + f * a.stride, a.n, 1, lds);
             if (threadIdx.x == 0) a.rec[f] = t;
         }
         return;
@@ -743,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void k_sub(long long begin, long long len, 
 // (matrix_free_system.cpp:457-463).  One partial per block.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_resid2(long long begin, long long len, const T* b, const T* ax, double* part) {
-    __shared__ double lds[kWaves];
+    __shared__ double lds[2 * kWaves];
     const long long stride = (long long)gridDim.x * kBlock;
     double s = 0.0;
     for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride) {

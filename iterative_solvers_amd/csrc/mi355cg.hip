@@ -41,7 +41,7 @@ int env_int(const char* name, int dflt) {
 
 inline long long round_up(long long v, long long m) { return (v + m - 1) / m * m; }
 
-constexpr int kRecHeader = 8;      // doubles reserved for the sums at the head of a slab record
+constexpr int kRecHeader = 16;     // doubles reserved for the sums (hi/lo pairs) and maxes at the head of a slab record
 
 struct EventPool {
     std::vector<hipEvent_t> ev;
@@ -952,9 +952,8 @@ int mi355cg_dist_reduce(mi355cg_handle c, int which, int with_rows, void* stream
     const Geom& g = c->g;
     RecordArgs a{};
     a.rec = which == 0 ? c->sumsA : c->sumsB; a.header = kRecHeader; a.row_slot = g.Pu;
-    if (which == 0) { a.part = c->partA; a.n = c->nA_dist; a.stride = c->strideA; a.nf = FA_COUNT; a.max_mask = 0u; }
-    else { a.part = c->partB; a.n = c->grid_update; a.stride = c->strideB; a.nf = FB_COUNT;
-           a.max_mask = (1u << FB_RMAX) | (1u << FB_DMAX) | (1u << FB_EMAX); }
+    if (which == 0) { a.part = c->partA; a.n = c->nA_dist; a.stride = c->strideA; a.nsum = kNumSumsA; a.lo_off = FA_LO; a.max_first = 0; a.nmax = 0; }
+    else { a.part = c->partB; a.n = c->grid_update; a.stride = c->strideB; a.nsum = kNumSumsB; a.lo_off = FB_LO; a.max_first = FB_RMAX; a.nmax = 3; }
     if (with_rows) {
         a.v = which == 0 ? c->p[c->cur] : c->r;
         a.off_lo = phys_start(g, g.y_lo) - g.base0; a.len_lo = g.y_lo <= g.half ? g.Pb : g.Pu;
@@ -962,6 +961,13 @@ int mi355cg_dist_reduce(mi355cg_handle c, int which, int with_rows, void* stream
     }
     hipLaunchKernelGGL(k_make_record, dim3(with_rows ? 1 + 32 : 1), dim3(kBlock), 0, st, a);
     HIPCK(hipGetLastError());
+    return MI355CG_OK;
+}
+int mi355cg_dist_record_layout(mi355cg_handle c, int* header, int* row_slot, int* width) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    if (header) *header = kRecHeader;
+    if (row_slot) *row_slot = c->g.Pu;
+    if (width) *width = c->rec_width;
     return MI355CG_OK;
 }
 int mi355cg_dist_sums_ptr(mi355cg_handle c, int which, void** dev_ptr, int* count) {

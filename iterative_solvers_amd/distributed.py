@@ -44,8 +44,6 @@ import torch.distributed as dist
 from . import _capi
 from .solver import default_params
 
-FA_COUNT, FB_COUNT = 2, 6          # fields of the stencil / update partial sums (cg_kernels.h)
-REC_HEADER = 8                     # doubles reserved for the sums at the head of a slab record
 
 
 def slab_rows(n: int, world: int, rank: int):
@@ -84,6 +82,9 @@ class SlabEngine:
         pb, pl = C.c_longlong(), C.c_longlong()
         _capi.check(self._lib.mi355cg_owned_range(self._h, C.byref(pb), C.byref(pl), None, None))
         self.packed_begin, self.packed_len = pb.value, pl.value
+        hdr = C.c_int()
+        _capi.check(self._lib.mi355cg_dist_record_layout(self._h, C.byref(hdr), None, None))
+        self.rec_header = hdr.value                         # doubles of sums/maxes at the head of a record
         self._sums = {}
         self._halo_cache = {}
         for which in (0, 1):
@@ -114,7 +115,7 @@ class SlabEngine:
         _capi.check(self._lib.mi355cg_dist_reduce(self._h, which, 1 if with_rows else 0, self._stream()))
 
     def record(self, which: int) -> torch.Tensor:
-        """This rank's record: [sums (REC_HEADER doubles) | first owned row | last owned row]."""
+        """This rank's record: [sums and maxes (rec_header doubles) | first owned row | last owned row]."""
         return self._sums[which]
 
     def scatter_ghosts(self, vector: int, gathered: torch.Tensor, rank: int):
@@ -264,7 +265,7 @@ class DistributedCG:
         self.halo = halo
         self.overlap = overlap and halo == "p2p"
         rec = engine.record(0)
-        self.W = rec.numel() if halo == "gather" else REC_HEADER       # doubles all-gathered per rank and phase
+        self.W = rec.numel() if halo == "gather" else engine.rec_header   # doubles all-gathered per rank and phase
         self.gA = torch.zeros(self.comm.world * self.W, dtype=torch.float64, device=rec.device)
         self.gB = torch.zeros(self.comm.world * self.W, dtype=torch.float64, device=rec.device)
 
@@ -278,7 +279,7 @@ class DistributedCG:
                 eng.scatter_ghosts(1 if which == 0 else 0, g, comm.rank)
         else:
             eng.reduce(which, with_rows=False)
-            comm.all_gather(self.gA if which == 0 else self.gB, eng.record(which)[:REC_HEADER])
+            comm.all_gather(self.gA if which == 0 else self.gB, eng.record(which)[:eng.rec_header])
 
     def solve(self, params: _capi.Params, callback=None) -> DistResults:
         eng, comm, W = self.eng, self.comm, self.W

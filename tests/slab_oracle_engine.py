@@ -38,6 +38,7 @@ class OracleSlabEngine:
         self.packed_begin, self.packed_len = self.own.start, self.own.stop - self.own.start
         self.b = np.zeros(self.U); self.b[self.own] = self.og.rhs()[self.own]
         self.u = np.zeros(self.U); self.u[self.own] = self.og.true_solution()[self.own]
+        self.rec_header = REC_HEADER
         self.row_w = n - 1                                  # widest row; records pad shorter rows with zeros
         self.W = REC_HEADER + 2 * self.row_w
         self._rec = {0: torch.zeros(self.W, dtype=torch.float64), 1: torch.zeros(self.W, dtype=torch.float64)}

@@ -90,6 +90,14 @@ def test_slabs_over_gloo_match_the_oracle_rel2(world, n, halo):
     assert int(r0["it"]) == ref.iterations
     assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
     assert abs(float(r0["rnorm2"]) - ref.r_norm) / ref.initial_r_norm <= 1e-12
+    # SURVEY 8e determinism requirement: the result must not depend on the number of GPUs.  The inner
+    # products are accumulated in double-double, so every decomposition takes bit-identical steps.
+    import iterative_solvers_amd as isa
+    s1 = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0)
+    sol1 = isa.MatrixFreeSolver(s1, s1.get_rhs(), 1e-8, 10 ** 5)
+    x1 = sol1.solve()
+    assert np.array_equal(x, x1) and float(r0["rnorm2"]) == sol1.last_results.r_norm2
+    assert np.array_equal(r, s1._handle.recursive_residual())
     # recursive residual of the slabs against the true residual of the assembled x
     assert np.abs(r - (og.rhs() - og.apply(x))).max() <= 1e-9 * np.abs(og.rhs()).max()
 
@@ -105,6 +113,15 @@ def test_slabs_over_gloo_msg_rule(halo):
     assert [int(c[0]) for c in r0["cbs"]] == [c[0] for c in ref.callbacks]
     assert np.abs(np.array(r0["cbs"])[:, 2] - np.array(ref.callbacks)[:, 2]).max() / ref.initial_r_norm2 <= 1e-12
     assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+    import iterative_solvers_amd as isa
+    s1 = isa.GridSystem(n, n, 1.0, 2.0, 1.0, 2.0)
+    m1 = isa.MSGSolver(s1, s1.get_rhs(), 1e-9, 10000)
+    m1.setPrecisionEps(1e-9); m1.setResidualEps(1e-9); m1.setExactErrorEps(-1.0)
+    got1 = []
+    m1.setIterationCallback(lambda *a: got1.append(a))
+    x1 = m1.solve(s1.get_true_solution_vector())
+    assert np.array_equal(x, x1)                                  # 2 slabs == 1 GPU, bit for bit
+    assert np.array_equal(np.array(r0["cbs"]), np.array(got1, dtype=float))
 
 
 def test_bench_distributed_leg_runs_under_torchrun_with_rccl():
