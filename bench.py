@@ -49,9 +49,23 @@ def cpu_baseline(n: int, iters: int):
     r = g.mf_solve(b=b, true_solution=u, eps=0.0, max_iterations=iters, diagnostics=False)
     dt = time.perf_counter() - t0
     assert r.iterations == iters
-    return {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"{iters} CG iterations of oracle/cg_oracle.c (MatrixFreeSolver loop without the "
-                      f"diagnostic second apply) at N={n}, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+    out = {"value": iters / dt, "unit": "iters/s", "cores": 1, "kind": "port",
+           "sample": f"{iters} CG iterations of oracle/cg_oracle.c (MatrixFreeSolver loop without the "
+                     f"diagnostic second apply) at N={n}, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+    try:        # the same loop on every host core (OpenMP build of the same source; BASELINE.md section 4 "ref-omp")
+        from oracle.oracle import mf_solve_all_cores
+        t0 = time.perf_counter()
+        mf_solve_all_cores(n, b, 0.0, 3)                                # calibration: keep this leg to about 10 s
+        per_it = (time.perf_counter() - t0) / 3
+        k = max(3, min(10 * iters, int(10.0 / max(per_it, 1e-4))))
+        t0 = time.perf_counter()
+        its, _, threads = mf_solve_all_cores(n, b, 0.0, k)
+        dt2 = time.perf_counter() - t0
+        out["all_cores"] = {"value": its / dt2, "unit": "iters/s", "cores": threads, "kind": "port-openmp",
+                            "sample": f"{its} iterations, {dt2:.1f} s, {threads} OpenMP threads"}
+    except Exception as e:                                           # never fail the bench on the baseline leg
+        out["all_cores"] = {"error": repr(e)[:200]}
+    return out
 
 
 def read_traffic():

@@ -330,3 +330,67 @@ void og_msg_solve(const og_grid *g, const double *b, const double *true_solution
     if (r_out) memcpy(r_out, r, sizeof(double) * n);
     free(x_prev); free(r); free(z); free(A_z); free(tmp);
 }
+
+
+/* ---- all-cores variant (timing baseline only) ----------------------------------------------------------------
+ * Same per-element arithmetic as og_apply / og_mf_solve, rows distributed over OpenMP threads; the dot products use
+ * an OpenMP reduction, so their summation order (hence the last bits) differs from the serial reference-faithful
+ * code above.  Built only into libcg_oracle_omp.so (-fopenmp); bench.py times it as the "all host cores" figure
+ * BASELINE.md section 4 calls ref-omp.  Never used as a parity checker. */
+#ifdef _OPENMP
+#include <omp.h>
+int og_omp_threads(void) { return omp_get_max_threads(); }
+
+static void og_apply_row(const og_grid *g, int yi, const double *x, double *y)
+{
+    const int sz = g->size;
+    const int x0 = yi <= g->m / 2 ? g->n / 2 + 1 : 1;
+    for (int xi = x0; xi < g->n; ++xi) {
+        if (og_is_boundary(g, xi, yi)) continue;
+        int row = og_position(g, xi, yi);
+        if (!(row >= 0 && row < sz)) continue;
+        double v = 0.0;
+        v += g->A * x[row];
+        if (!is_left(g, xi - 1, yi)) { int col = og_position(g, xi - 1, yi); if (col >= 0 && col < sz) v += g->x_k * x[col]; }
+        if (!is_right(g, xi + 1, yi)) { int col = og_position(g, xi + 1, yi); if (col >= 0 && col < sz) v += g->x_k * x[col]; }
+        if (!is_top(g, xi, yi + 1)) { int col = og_position(g, xi, yi + 1); if (col >= 0 && col < sz) v += g->y_k * x[col]; }
+        if (!is_bottom(g, xi, yi - 1)) { int col = og_position(g, xi, yi - 1); if (col >= 0 && col < sz) v += g->y_k * x[col]; }
+        y[row] = v;
+    }
+}
+void og_apply_omp(const og_grid *g, const double *x, double *y)
+{
+#pragma omp parallel for schedule(static)
+    for (int yi = 1; yi < g->m; ++yi) og_apply_row(g, yi, x, y);
+}
+static double og_dot_omp(const double *a, const double *b, long n)
+{
+    double result = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : result)
+    for (long i = 0; i < n; ++i) result += a[i] * b[i];
+    return result;
+}
+/* MatrixFreeSolver loop without the diagnostics, all cores.  Returns iterations done. */
+int og_mf_solve_omp(const og_grid *g, const double *b, double eps, int max_iterations, double *x)
+{
+    const int n = g->size;
+    double *r = malloc(sizeof(double) * n), *p = malloc(sizeof(double) * n), *Ap = malloc(sizeof(double) * n);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; p[i] = b[i]; }
+    double r_norm = sqrt(og_dot_omp(r, r, n));
+    const double initial = r_norm;
+    int it;
+    for (it = 0; it < max_iterations && r_norm > eps * initial; ++it) {
+        og_apply_omp(g, p, Ap);
+        const double pAp = og_dot_omp(p, Ap, n), rr = og_dot_omp(r, r, n), alpha = rr / pAp;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i) { x[i] += alpha * p[i]; r[i] -= alpha * Ap[i]; }
+        const double rr_new = og_dot_omp(r, r, n), beta = rr_new / rr;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i) p[i] = r[i] + beta * p[i];
+        r_norm = sqrt(rr_new);
+    }
+    free(r); free(p); free(Ap);
+    return it;
+}
+#endif

@@ -216,3 +216,39 @@ def dot(a: np.ndarray, b: np.ndarray) -> float:
 def max_norm(a: np.ndarray) -> float:
     a = np.ascontiguousarray(a, dtype=np.float64)
     return lib().og_max_norm(a, a.size)
+
+
+# ---- all-cores timing baseline (libcg_oracle_omp.so); not a parity checker -------------------------------
+_LIB_OMP_PATH = os.path.join(_HERE, "_build", "libcg_oracle_omp.so")
+_lib_omp = None
+
+
+def lib_omp():
+    global _lib_omp
+    if _lib_omp is None:
+        build()
+        if not os.path.exists(_LIB_OMP_PATH):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        L = C.CDLL(_LIB_OMP_PATH)
+        GP = C.POINTER(_Grid)
+        L.og_grid_init.argtypes = [GP, C.c_int, C.c_int] + [C.c_double] * 4
+        L.og_grid_init.restype = None
+        L.og_rhs.argtypes = [GP, _DP]
+        L.og_rhs.restype = None
+        L.og_omp_threads.restype = C.c_int
+        L.og_mf_solve_omp.argtypes = [GP, _DP, C.c_double, C.c_int, _DP]
+        L.og_mf_solve_omp.restype = C.c_int
+        L.og_apply_omp.argtypes = [GP, _DP, _DP]
+        L.og_apply_omp.restype = None
+        _lib_omp = L
+    return _lib_omp
+
+
+def mf_solve_all_cores(n: int, b: np.ndarray, eps: float, max_iterations: int):
+    """(iterations, x, threads): the MatrixFreeSolver loop on every host core."""
+    L = lib_omp()
+    g = _Grid()
+    L.og_grid_init(C.byref(g), n, n, 1.0, 2.0, 1.0, 2.0)
+    x = np.empty(g.size)
+    its = L.og_mf_solve_omp(C.byref(g), np.ascontiguousarray(b, dtype=np.float64), eps, max_iterations, x)
+    return its, x, L.og_omp_threads()
