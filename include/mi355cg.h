@@ -97,6 +97,14 @@ typedef struct mi355cg_results {
  * n == m, even, >= 6 is accepted (the reference's index map is only consistent there).         */
 int  mi355cg_create(int n, int m, double a, double b, double c, double d,
                     int dtype, int device, mi355cg_handle *out);
+/* Generic operator: any caller-supplied CSR matrix (int32 row_map[nrows+1], entries, fp64 values), the contract of
+ * Solver(const KokkosCrsMatrix& a, const KokkosVector& b, ...) (solver/solver.hpp:33-39).  Vectors of such a handle are
+ * plain length-nrows arrays; set_rhs / set_true_solution / apply / solve / get_solution work as on a grid handle
+ * (both stop rules; no per-iteration diagnostics).  A x = KokkosSparse::spmv("N",1,A,x,0,y) (solver/msg_solver.cpp:93),
+ * summed per row in entry order. */
+int  mi355cg_create_csr(long long nrows, const int *row_map, const int *entries, const double *values,
+                        int device, mi355cg_handle *out);
+int  mi355cg_set_true_solution(mi355cg_handle h, const double *u);   /* u of the error criterion / norm (MSG rule) */
 void mi355cg_destroy(mi355cg_handle h);
 const char *mi355cg_last_error(void);
 const char *mi355cg_version(void);

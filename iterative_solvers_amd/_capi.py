@@ -15,7 +15,7 @@ RULE_MSG_MAXNORM, RULE_REL_2NORM = 0, 1
 STOP_ITERATIONS, STOP_PRECISION, STOP_RESIDUAL, STOP_EXACT_ERROR, STOP_INTERRUPTED = range(5)
 
 EXPORTS = [
-    "mi355cg_create", "mi355cg_destroy", "mi355cg_last_error", "mi355cg_version", "mi355cg_size",
+    "mi355cg_create", "mi355cg_create_csr", "mi355cg_set_true_solution", "mi355cg_destroy", "mi355cg_last_error", "mi355cg_version", "mi355cg_size",
     "mi355cg_get_rhs", "mi355cg_get_true_solution", "mi355cg_get_node_coords", "mi355cg_set_rhs",
     "mi355cg_apply", "mi355cg_apply_device", "mi355cg_default_params", "mi355cg_solve",
     "mi355cg_get_solution", "mi355cg_get_recursive_residual", "mi355cg_get_true_residual",
@@ -75,6 +75,9 @@ def load():
     L = C.CDLL(path)
     H = C.c_void_p
     L.mi355cg_create.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.POINTER(H)]
+    _IPn = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    L.mi355cg_create_csr.argtypes = [C.c_longlong, _IPn, _IPn, _DP, C.c_int, C.POINTER(H)]
+    L.mi355cg_set_true_solution.argtypes = [H, _DP]
     L.mi355cg_destroy.argtypes = [H]
     L.mi355cg_destroy.restype = None
     L.mi355cg_last_error.restype = C.c_char_p

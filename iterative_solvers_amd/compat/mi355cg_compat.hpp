@@ -93,6 +93,11 @@ struct Context {
         : n(n_), m(m_), a(a_), b(b_), c(c_), d(d_) {
         check(mi355cg_create(n, m, a, b, c, d, MI355CG_F64, device, &h));
     }
+    bool csr = false;
+    // caller-supplied CSR matrix: the generic path of Solver(a, b, ...) (mi355cg_create_csr)
+    Context(long long nrows, const int* row_map, const int* entries, const double* values, int device = 0) : csr(true) {
+        check(mi355cg_create_csr(nrows, row_map, entries, values, device, &h));
+    }
     ~Context() { mi355cg_destroy(h); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
@@ -116,8 +121,17 @@ public:
     mutable std::vector<Scalar> values;
     CrsMatrix() = default;
     explicit CrsMatrix(std::shared_ptr<mi355cg_compat::Context> c) : ctx_(std::move(c)) {}
+    // KokkosSparse's raw-pointer constructor: a matrix of the caller's own (copied, then resident on the GPU)
+    CrsMatrix(const std::string&, Ordinal nrows, Ordinal ncols, size_t annz, const Scalar* val, const Offset* rowmap, const Ordinal* cols) {
+        if (nrows != ncols) throw std::invalid_argument("CrsMatrix: the CG path needs a square matrix");
+        graph.row_map.assign(rowmap, rowmap + nrows + 1);
+        graph.entries.assign(cols, cols + annz);
+        values.assign(val, val + annz);
+        built_ = true;
+        ctx_ = std::make_shared<mi355cg_compat::Context>((long long)nrows, graph.row_map.data(), graph.entries.data(), values.data());
+    }
     const std::shared_ptr<mi355cg_compat::Context>& context() const { return ctx_; }
-    long long numRows() const { return ctx_ ? ctx_->size() : 0; }
+    long long numRows() const { return ctx_ ? ctx_->size() : 0; }   // grid operator or caller-supplied matrix
     long long numCols() const { return numRows(); }
     long long nnz() const { materialize(); return (long long)values.size(); }
     void materialize() const { if (!built_ && ctx_) { build(); built_ = true; } }
@@ -277,6 +291,8 @@ public:
         if (!a.context()) throw std::runtime_error("MSGSolver: the matrix is not a GridSystem operator");
         mi355cg_handle h = a.context()->h;
         mi355cg_compat::check(mi355cg_set_rhs(h, b.data()));
+        if (a.context()->csr && true_solution.extent(0) > 0)       // a generic matrix has no built-in exact solution
+            mi355cg_compat::check(mi355cg_set_true_solution(h, true_solution.data()));
         mi355cg_params p;
         mi355cg_default_params(&p, MI355CG_RULE_MSG_MAXNORM);
         p.max_iterations = maxIterations;

@@ -3,6 +3,7 @@
 // No CPU fallback: every compute entry point needs a working HIP device.
 #include "../../include/mi355cg.h"
 #include "cg_kernels.h"
+#include "csr_kernels.h"
 #include "grid_setup.h"
 
 #include <algorithm>
@@ -91,6 +92,11 @@ struct mi355cg_ctx {
 
     std::vector<double> rhs_h, u_h;     // packed host copies (owned range)
     bool have_u_dev = false, solved = false;
+    // generic CSR handle (mi355cg_create_csr): vectors are plain length-n arrays, the operator is this matrix
+    bool is_csr = false;
+    long long csr_n = 0, csr_nnz = 0;
+    int *csr_row_map = nullptr, *csr_entries = nullptr; double* csr_values = nullptr;
+    int grid_csr = 0;
     int cur = 0;                        // p[cur] holds the current direction after the last stencil
     int nA_dist = 0;                    // slab mode: stencil partial slots written by the last stencil phase
 
@@ -323,6 +329,11 @@ IterCfg make_cfg(const mi355cg_params* prm) {
 
 template <typename T>
 int upload_packed(mi355cg_ctx* c, const double* host_packed, T* storage) {
+    if (c->is_csr) {                                        // no layout conversion: the caller's order is the storage order
+        HIPCK(hipMemcpyAsync(storage, host_packed, sizeof(double) * c->pk_len, hipMemcpyHostToDevice, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        return MI355CG_OK;
+    }
     if (c->is_slab) HIPCK(hipDeviceSynchronize());
     HIPCK(hipMemcpyAsync(c->packed, host_packed, sizeof(double) * c->pk_len, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL((k_unpack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), c->packed, storage);
@@ -332,6 +343,11 @@ int upload_packed(mi355cg_ctx* c, const double* host_packed, T* storage) {
 }
 template <typename T>
 int download_packed(mi355cg_ctx* c, const T* storage, double* host_packed) {
+    if (c->is_csr) {
+        HIPCK(hipMemcpyAsync(host_packed, storage, sizeof(double) * c->pk_len, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        return MI355CG_OK;
+    }
     if (c->is_slab) HIPCK(hipDeviceSynchronize());      // slab phases run on the caller's streams
     hipLaunchKernelGGL((k_pack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), storage, c->packed);
     HIPCK(hipGetLastError());
@@ -383,6 +399,104 @@ void prof_collect(mi355cg_ctx* c) {
         c->ev_pairs[k].clear();
     }
     c->events.reset();
+}
+
+}  // namespace
+
+// ---- generic CSR handles ----------------------------------------------------------------------------------
+namespace {
+
+CsrView csr_view(const mi355cg_ctx* c) { return CsrView{c->csr_n, c->csr_row_map, c->csr_entries, c->csr_values}; }
+
+void launch_csr_spmv(mi355cg_ctx* c, const double* x, double* y, const double* r, const CgState* s_in, double* partA) {
+    SpmvArgs a{};
+    a.A = csr_view(c); a.x = x; a.y = y; a.r = r; a.s_in = s_in; a.partA = partA; a.strideA = c->strideA;
+    hipLaunchKernelGGL(k_csr_spmv, dim3(c->grid_csr), dim3(kBlock), 0, c->stream, a);
+}
+
+// CG on a caller-supplied matrix: xpay (decision + direction), spmv (+ dots), update.  Same device-side state
+// machine, stop rules, callback cadence and result fields as the stencil path.
+int solve_csr(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
+              const volatile int* stop_flag, mi355cg_results* out) {
+    if (prm->diagnostics) return fail(MI355CG_ERR_INVALID, "per-iteration diagnostics are not available on CSR handles");
+    const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
+    IterCfg cfg = make_cfg(prm);
+    if (cfg.has_u && !c->have_u_dev) { cfg.has_u = false; cfg.rp.use_u = 0; }      // no true solution was supplied
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t bytes = sizeof(double) * c->storage_len;
+    HIPCK(hipMemsetAsync(c->x, 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->p[0], 0, bytes, c->stream));
+    HIPCK(hipMemsetAsync(c->ap, 0, bytes, c->stream));
+    HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
+    c->cur = 0;
+    const PartSrc pA{c->partA, c->grid_csr, c->strideA, 1};
+    auto update = [&](bool init, bool with_u) {
+        UpdateArgs<double> a{};
+        a.begin = 0; a.nvec = c->csr_n;
+        a.x = c->x; a.r = c->r; a.p = c->p[0]; a.ap = c->ap; a.u = c->u;
+        a.partA = pA.ptr; a.nA = pA.n; a.strideA = pA.fstride; a.esA = 1;
+        a.partB = c->partB; a.strideB = c->strideB;
+        a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = 0; a.nt = 0; a.light = 0;
+        if (with_u) hipLaunchKernelGGL((k_update<double, 1, true>), dim3(c->grid_update), dim3(kBlock), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_update<double, 1, false>), dim3(c->grid_update), dim3(kBlock), 0, c->stream, a);
+    };
+    update(true, cfg.has_u);
+    HIPCK(hipGetLastError());
+    auto poll = [&]() -> int {
+        launch_check(c, cfg, c->stream, own_partB(c));
+        HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipMemcpyAsync(c->hist_h, c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(hipStreamSynchronize(c->stream));
+        return MI355CG_OK;
+    };
+    if (int rc = poll()) return rc;
+    const double initial_rnorm2 = c->summary_h->rnorm2;
+    if (msg && cb) cb(user, 0, DBL_MAX, c->summary_h->rmax, cfg.has_u ? c->summary_h->emax : DBL_MAX);
+    const int every = prm->callback_every;
+    const int sync_every = std::min(prm->sync_every > 0 ? prm->sync_every : (msg ? 100 : 200), kHist);
+    int it_done = 0;
+    bool interrupted = false;
+    while (!c->summary_h->done) {
+        if (stop_flag && *stop_flag) { interrupted = true; break; }
+        int m = std::min(sync_every, prm->max_iterations - it_done);
+        if (msg && every > 0) m = std::min(m, every - it_done % every);
+        if (m <= 0) m = 1;
+        for (int k = 0; k < m; ++k) {
+            XpayArgs xa{};
+            xa.n = c->csr_n; xa.r = c->r; xa.p = c->p[0];
+            xa.partB = c->partB; xa.nB = c->grid_update; xa.strideB = c->strideB; xa.esB = 1;
+            xa.s_in = c->sB; xa.s_out = c->sA; xa.hist = c->hist; xa.rp = cfg.rp; xa.want_diag = 0;
+            hipLaunchKernelGGL(k_csr_xpay, dim3(c->grid_update), dim3(kBlock), 0, c->stream, xa);
+            launch_csr_spmv(c, c->p[0], c->ap, c->r, c->sA, c->partA);
+            update(false, cfg.has_u);
+        }
+        HIPCK(hipGetLastError());
+        if (int rc = poll()) return rc;
+        const int it_now = c->summary_h->it;
+        if (msg && cb)
+            for (int it = it_done + 1; it <= it_now; ++it) {
+                const bool stopped_here = c->summary_h->done && c->summary_h->reason != MI355CG_STOP_ITERATIONS && it == it_now;
+                if ((it == 1 || (every > 0 && it % every == 0)) && !stopped_here) {
+                    const HistEntry& h = c->hist_h[it % kHist];
+                    cb(user, it, h.dmax, h.rmax, cfg.has_u ? h.emax : DBL_MAX);
+                }
+            }
+        it_done = it_now;
+    }
+    const CgState fin = *c->summary_h;
+    c->solved = true;
+    mi355cg_results res{};
+    res.iterations = fin.it;
+    res.converged = interrupted ? 0 : fin.converged;
+    res.stop_reason = interrupted ? MI355CG_STOP_INTERRUPTED : fin.reason;
+    res.final_residual_norm = fin.rmax;
+    res.final_precision = fin.it > 0 ? fin.dmax : DBL_MAX;
+    res.final_error_norm = cfg.has_u ? fin.emax : DBL_MAX;
+    res.r_norm2 = fin.rnorm2; res.initial_r_norm2 = initial_rnorm2;
+    res.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (msg && cb) cb(user, res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm);
+    if (out) *out = res;
+    return MI355CG_OK;
 }
 
 }  // namespace
@@ -593,6 +707,67 @@ int mi355cg_create_slab(int n, int m, double a, double b, double c_, double d, i
     return create_impl(n, m, a, b, c_, d, dtype, device, y_lo, y_hi, true, out);
 }
 
+int mi355cg_create_csr(long long nrows, const int* row_map, const int* entries, const double* values,
+                       int device, mi355cg_handle* out) {
+    if (!out) return fail(MI355CG_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (nrows <= 0 || !row_map || !entries || !values) return fail(MI355CG_ERR_INVALID, "bad CSR arguments");
+    if (row_map[0] != 0) return fail(MI355CG_ERR_INVALID, "row_map[0] must be 0");
+    const long long nnz = row_map[nrows];
+    for (long long i = 0; i < nrows; ++i) if (row_map[i + 1] < row_map[i]) return fail(MI355CG_ERR_INVALID, "row_map is not monotone at row %lld", i);
+    for (long long j = 0; j < nnz; ++j) if (entries[j] < 0 || entries[j] >= nrows) return fail(MI355CG_ERR_INVALID, "column index %d out of range at entry %lld", entries[j], j);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MI355CG_ERR_HIP, "no HIP device available (libmi355cg has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MI355CG_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    HIPCK(hipSetDevice(device));
+    mi355cg_ctx* c = new mi355cg_ctx();
+    c->device = device; c->dtype = MI355CG_F64; c->is_csr = true;
+    c->csr_n = nrows; c->csr_nnz = nnz;
+    c->gp.size = nrows; c->pk_begin = 0; c->pk_len = nrows; c->storage_len = nrows;
+    c->g.own_begin = 0; c->g.own_len = nrows;
+    const long long nblk = (nrows + kBlock - 1) / kBlock;
+    c->grid_csr = (int)std::max<long long>(1, std::min<long long>(2048, nblk));
+    c->grid_update = (int)std::max<long long>(1, std::min<long long>(512, nblk));
+    c->grid_stencil = c->grid_csr;
+    c->strideA = c->grid_csr; c->strideB = c->grid_update;
+    c->update_mode = 0;
+    int rc = MI355CG_OK;
+    auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "hipStreamCreate failed"); return cleanup(); }
+    double** vecs[] = {&c->x, &c->r, &c->p[0], &c->p[1], &c->ap, &c->b, &c->u};
+    for (auto v : vecs) if ((rc = alloc_vec(v, nrows))) return cleanup();
+    if ((rc = alloc_vec(&c->partA, (long long)FA_COUNT * c->strideA))) return cleanup();
+    if ((rc = alloc_vec(&c->partB, (long long)FB_COUNT * c->strideB))) return cleanup();
+    if ((rc = alloc_vec(&c->partR, 2048))) return cleanup();
+    if (hipMalloc((void**)&c->csr_row_map, sizeof(int) * (nrows + 1)) != hipSuccess || hipMalloc((void**)&c->csr_entries, sizeof(int) * std::max<long long>(nnz, 1)) != hipSuccess ||
+        hipMalloc((void**)&c->csr_values, sizeof(double) * std::max<long long>(nnz, 1)) != hipSuccess ||
+        hipMalloc((void**)&c->sA, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->sB, sizeof(CgState)) != hipSuccess ||
+        hipMalloc((void**)&c->summary, sizeof(CgState)) != hipSuccess || hipMalloc((void**)&c->hist, sizeof(HistEntry) * kHist) != hipSuccess ||
+        hipHostMalloc((void**)&c->summary_h, sizeof(CgState)) != hipSuccess || hipHostMalloc((void**)&c->hist_h, sizeof(HistEntry) * kHist) != hipSuccess ||
+        hipHostMalloc((void**)&c->partR_h, sizeof(double) * 2048) != hipSuccess) {
+        rc = fail(MI355CG_ERR_HIP, "allocation failed"); return cleanup();
+    }
+    if (hipMemcpy(c->csr_row_map, row_map, sizeof(int) * (nrows + 1), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->csr_entries, entries, sizeof(int) * nnz, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->csr_values, values, sizeof(double) * nnz, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(MI355CG_ERR_HIP, "CSR upload failed"); return cleanup();
+    }
+    hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
+    hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
+    c->rhs_h.assign(nrows, 0.0); c->u_h.assign(nrows, 0.0);
+    *out = c;
+    return MI355CG_OK;
+}
+
+int mi355cg_set_true_solution(mi355cg_handle c, const double* u) {
+    if (!c || !u) return fail(MI355CG_ERR_INVALID, "null argument");
+    HIPCK(hipSetDevice(c->device));
+    std::memcpy(c->u_h.data(), u, sizeof(double) * c->pk_len);
+    if (int rc = upload_packed<double>(c, c->u_h.data(), c->u)) return rc;
+    c->have_u_dev = true;
+    return MI355CG_OK;
+}
+
 void mi355cg_destroy(mi355cg_handle c) {
     if (!c) return;
     hipSetDevice(c->device);
@@ -600,6 +775,9 @@ void mi355cg_destroy(mi355cg_handle c) {
     void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->xf, c->rf, c->pf[0], c->pf[1], c->apf, c->bf,
                    c->packed, c->zero_blk, c->trash_blk, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
     for (void* p : dev) if (p) hipFree(p);
+    if (c->csr_row_map) hipFree(c->csr_row_map);
+    if (c->csr_entries) hipFree(c->csr_entries);
+    if (c->csr_values) hipFree(c->csr_values);
     if (c->summary_h) hipHostFree(c->summary_h);
     if (c->hist_h) hipHostFree(c->hist_h);
     if (c->partR_h) hipHostFree(c->partR_h);
@@ -623,6 +801,7 @@ int mi355cg_get_true_solution(mi355cg_handle c, double* out) {
 }
 int mi355cg_get_node_coords(mi355cg_handle c, double* xs, double* ys) {
     if (!c || !xs || !ys) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (c->is_csr) return fail(MI355CG_ERR_INVALID, "a CSR handle has no grid coordinates");
     grid_fill_rows(c->gp, c->g.y_lo, c->g.y_hi, nullptr, nullptr, xs, ys);
     return MI355CG_OK;
 }
@@ -636,6 +815,12 @@ int mi355cg_set_rhs(mi355cg_handle c, const double* b) {
 int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
     if (!c || !x_dev || !y_dev) return fail(MI355CG_ERR_INVALID, "null argument");
     HIPCK(hipSetDevice(c->device));
+    if (c->is_csr) {
+        launch_csr_spmv(c, x_dev, y_dev, nullptr, nullptr, nullptr);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(c->stream));
+        return MI355CG_OK;
+    }
     // p[1] <- unpack(x); ap <- A p[1]; y <- pack(ap).  (Scratch use only outside a solve.)
     hipLaunchKernelGGL((k_unpack<double>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), x_dev, c->p[1]);
     launch_apply<double, 2>(c, c->p[1], c->ap);
@@ -648,6 +833,12 @@ int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
 int mi355cg_apply(mi355cg_handle c, const double* x, double* y) {
     if (!c || !x || !y) return fail(MI355CG_ERR_INVALID, "null argument");
     HIPCK(hipSetDevice(c->device));
+    if (c->is_csr) {
+        if (int rc = upload_packed<double>(c, x, c->p[1])) return rc;
+        launch_csr_spmv(c, c->p[1], c->ap, nullptr, nullptr, nullptr);
+        HIPCK(hipGetLastError());
+        return download_packed<double>(c, c->ap, y);
+    }
     if (int rc = upload_packed<double>(c, x, c->p[1])) return rc;
     launch_apply<double, 2>(c, c->p[1], c->ap);
     HIPCK(hipGetLastError());
@@ -674,6 +865,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
     if (prm->rule != MI355CG_RULE_MSG_MAXNORM && prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "unknown rule %d", prm->rule);
     HIPCK(hipSetDevice(c->device));
+    if (c->is_csr) return solve_csr(c, prm, cb, user, stop_flag, out);
     if (c->dtype == MI355CG_F32_MIXED) return solve_mixed(c, prm, cb, user, stop_flag, out);
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
     IterCfg cfg = make_cfg(prm);
@@ -847,7 +1039,8 @@ int mi355cg_get_true_residual(mi355cg_handle c, double* out) {
     if (!c->solved) return fail(MI355CG_ERR_STATE, "no solve has run on this handle");
     HIPCK(hipSetDevice(c->device));
     // residual = A x - b   (dirichlet_solver.cpp:147-161); scratch: A x in ap, difference in the inactive direction buffer
-    launch_apply<double, 2>(c, c->x, c->ap);
+    if (c->is_csr) launch_csr_spmv(c, c->x, c->ap, nullptr, nullptr, nullptr);
+    else launch_apply<double, 2>(c, c->x, c->ap);
     double* scratch = c->p[c->cur ^ 1];
     hipLaunchKernelGGL((k_sub<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->ap, c->b, scratch);
     HIPCK(hipGetLastError());

@@ -54,6 +54,28 @@ class _Handle:
         _capi.check(rc)
         self.size = int(self._lib.mi355cg_size(self._h))
 
+    @classmethod
+    def from_csr(cls, row_map, entries, values, device=0):
+        """Handle for a caller-supplied CSR matrix (mi355cg_create_csr)."""
+        self = cls.__new__(cls)
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        row_map = np.ascontiguousarray(row_map, dtype=np.int32)
+        entries = np.ascontiguousarray(entries, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        rc = self._lib.mi355cg_create_csr(len(row_map) - 1, row_map, entries, values, int(device), C.byref(self._h))
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(self._lib.mi355cg_last_error().decode())
+        _capi.check(rc)
+        self.size = int(self._lib.mi355cg_size(self._h))
+        return self
+
+    def set_true_solution(self, u):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if u.shape != (self.size,):
+            raise ValueError(f"true solution has shape {u.shape}, expected ({self.size},)")
+        _capi.check(self._lib.mi355cg_set_true_solution(self._h, u))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.mi355cg_destroy(self._h)
@@ -166,6 +188,20 @@ class GridSystem(MatrixFreeSystem):
         return (float(xs[solution_index]), float(ys[solution_index]))
 
 
+class CrsMatrix:
+    """A caller-supplied sparse matrix (KokkosCrsMatrix, solver/solver.hpp:15) as the operator of
+    `MSGSolver(a, b, ...)` / `MatrixFreeSolver(a, b, ...)`: the generic path of the abstract `Solver` contract."""
+
+    def __init__(self, row_map, entries, values, device: int = 0):
+        self._handle = _Handle.from_csr(row_map, entries, values, device=device)
+
+    def numRows(self): return self._handle.size
+    def numCols(self): return self._handle.size
+    def size(self): return self._handle.size
+    def apply(self, x): return self._handle.apply(x)
+    def __mul__(self, x): return self.apply(x)
+
+
 class MatrixFreeSolver:
     """solver/matrix_free_system.hpp:73-127, MatrixFreeSolver::solve (.cpp:383-482):
     textbook CG, relative 2-norm stop rule."""
@@ -243,6 +279,8 @@ class MSGSolver:
         self._stop.value = 0                                     # msg_solver.cpp:12-13
         h = self.a._handle
         h.set_rhs(self.b)
+        if isinstance(self.a, CrsMatrix) and true_solution is not None and len(true_solution) > 0:
+            h.set_true_solution(true_solution)                   # a generic matrix has no built-in exact solution
         p = default_params(_capi.RULE_MSG_MAXNORM)
         p.max_iterations = self.maxIterations
         p.eps_precision, p.eps_residual, p.eps_exact_error = self.eps_precision, self.eps_residual, self.eps_exact_error

@@ -36,6 +36,19 @@ int main(int argc, char** argv) {
                     solver.getIterations(), solver.hasConverged() ? 1 : 0, (int)solver.getStopReason(),
                     solver.getFinalResidualNorm(), grid.get_matrix().nnz());
         jvec("msg_x", xs); jvec("msg_residual", res); jvec("msg_cb_its", cb_its);
+        {   // the abstract Solver contract with a matrix of the caller's own: the grid's CSR arrays re-wrapped
+            const KokkosCrsMatrix& G = grid.get_matrix();
+            G.materialize();
+            KokkosCrsMatrix mine("A", (int)G.numRows(), (int)G.numCols(), G.values.size(), G.values.data(),
+                                 G.graph.row_map.data(), G.graph.entries.data());
+            MSGSolver s2(mine, grid.get_rhs(), 1e-9, max_it);
+            s2.setVerbose(false);
+            KokkosVector x2 = s2.solve(u);
+            bool same = s2.getIterations() == solver.getIterations() && s2.getStopReason() == solver.getStopReason();
+            for (int i = 0; i < n && same; ++i) same = x2(i) == x(i);
+            std::printf("\"csr_same_as_grid\": %d, \"csr_error_norm_equal\": %d,\n", same ? 1 : 0,
+                        s2.getFinalErrorNorm() == solver.getFinalErrorNorm() ? 1 : 0);
+        }
         auto nc = grid.get_node_coordinates(0);
         std::printf("\"node0\": [%.17g, %.17g],\n", nc.x, nc.y);
     }

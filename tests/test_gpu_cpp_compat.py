@@ -50,6 +50,7 @@ def test_cpp_dropin_matches_oracle(N):
     assert np.array_equal(np.array(j["msg_residual"]), og.apply(x) - og.rhs())          # spmv shim = bit-exact operator
     assert abs(j["msg_rmax"] - ref.final_residual_norm) / ref.initial_r_norm2 <= 1e-12
     assert j["msg_nnz"] == len(og.csr()[2])
+    assert (j["csr_same_as_grid"], j["csr_error_norm_equal"]) == (1, 1)      # generic CSR path == stencil path, bit for bit
     xs, ys = og.node_coords()
     assert j["node0"] == [xs[0], ys[0]]
     # DirichletSolver flow (error criterion off by default)
