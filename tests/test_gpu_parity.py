@@ -406,3 +406,27 @@ def test_kernel_timing_hooks(isa):
     assert n0 == n1 == 50 and 0 < ms0 < 5 and 0 < ms1 < 5
     lay = h.layout()
     assert lay["pitch_upper"] % 32 == 0 and lay["pitch_bottom"] % 32 == 0 and lay["padded_len"] >= s.size()
+
+
+def test_n2048_against_long_oracle_runs(isa):
+    """N = 2048 (3.1 M unknowns): iteration counts, stop reason and final norms of the CPU oracle's 11- and 14-minute
+    serial solves (tests/golden/oracle_n2048.json, made by tests/golden/make_oracle_n2048.py)."""
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_n2048.json")) as f:
+        ref = json.load(f)
+    s = isa.GridSystem(2048, 2048, 1.0, 2.0, 1.0, 2.0)
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+    sol.solve()
+    mf = ref["mf_2048"]
+    assert sol.getIterations() == mf["iterations"]
+    # ||b||_2 itself: the oracle's serial sum over 3.1 M squares is off by 9e-12 relative (the GPU's double-double value
+    # agrees with math.fsum, see test_dot_products_are_more_accurate_than_serial)
+    assert sol.last_results.initial_r_norm2 == pytest.approx(mf["initial_r_norm"], rel=1e-10)
+    assert abs(sol.last_results.r_norm2 - mf["r_norm"]) / mf["initial_r_norm"] <= REL_TOL
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+    m.setPrecisionEps(1e-8); m.setResidualEps(1e-8); m.setExactErrorEps(-1.0)
+    m.solve(s.get_true_solution_vector())
+    mr = ref["msg_2048"]
+    assert (m.getIterations(), int(m.getStopReason())) == (mr["iterations"], mr["stop_reason"])
+    assert abs(m.getFinalResidualNorm() - mr["final_residual_norm"]) / mf["initial_r_norm"] <= REL_TOL
+    assert m.getFinalErrorNorm() == pytest.approx(mr["final_error_norm"], rel=1e-6)
