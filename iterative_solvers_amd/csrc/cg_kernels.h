@@ -57,6 +57,7 @@ struct WorkList { Panel p[kMaxPanels]; int np; int nitems; };
 struct CgState {
     double alpha, beta;
     double rr;          // (r, r) of the current residual
+    double rr_prev;     // (r, r) one decision earlier (lets a stopped solve resume with the right beta denominator)
     double rz;          // MSG: (r, z) of the current iteration (denominator of the next beta)
     double r0norm;      // ||r0||_2
     double rnorm2;      // ||r||_2
@@ -192,7 +193,7 @@ __device__ inline Decision decide_after_update(const CgState& s, const RuleParam
 
 __device__ inline void write_state_after_decision(CgState* out, HistEntry* hist, const CgState& s, const Decision& d) {
     CgState o = s;
-    o.rr = d.rr; o.rnorm2 = d.rnorm2; o.r0norm = d.r0norm; o.beta = d.beta;
+    o.rr_prev = s.rr; o.rr = d.rr; o.rnorm2 = d.rnorm2; o.r0norm = d.r0norm; o.beta = d.beta;
     o.rmax = d.rmax; o.dmax = d.dmax; o.emax = d.emax; o.d2 = d.d2; o.e2 = d.e2;
     o.done = d.done; o.reason = d.reason; o.converged = d.converged;
     *out = o;
@@ -427,6 +428,7 @@ struct UpdateArgs {
     int reverse;               // flat kernel: sweep the range from its end to its start
     int nt;                    // NT_B_* cache-policy bits
     int light;                 // 1: r -= alpha*Ap only (the x update rides in the next stencil launch, see XUPD)
+    double r0norm_resume;      // init == 2 (resume after a residual replacement): the new reference norm
 };
 
 template <typename T, int VEC, bool HAS_U>
@@ -435,8 +437,16 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     __shared__ double lds[2 * kWaves];
     CgState s;
     double alpha_d = 0.0, rz = 0.0;
-    if (a.init) {
+    if (a.init == 1) {
         s = CgState{}; s.first = 1; s.it = 0;
+    } else if (a.init == 2) {
+        // Resume after a residual replacement (mixed precision): r was overwritten with the freshly computed true
+        // residual.  Measure it (alpha = 0 leaves x and r untouched) and re-arm the state WITHOUT restarting CG: the
+        // direction is kept, the iteration count continues, the pending x update is gone (flushed by the host), and
+        // the beta of the next step divides by the (r, r) the interrupted step would have used.
+        s = *a.s_in;
+        if (s.done) s.rr = s.rr_prev;
+        s.done = 0; s.reason = 0; s.converged = 0; s.alpha = 0.0; s.r0norm = a.r0norm_resume;
     } else {
         s = *a.s_in;
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }

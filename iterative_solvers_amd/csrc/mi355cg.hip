@@ -278,7 +278,7 @@ PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, c->grid_stenc
 
 template <typename T, int VEC>
 void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, bool init,
-                   hipStream_t stream, const PartSrc& pa) {
+                   hipStream_t stream, const PartSrc& pa, double resume_r0norm = -1.0) {
     UpdateArgs<T> a{};
     a.begin = c->g.own_begin / VEC; a.nvec = c->g.own_len / VEC;
     a.x = x; a.r = r; a.p = p; a.ap = ap; a.u = u;
@@ -286,8 +286,9 @@ void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, c
     a.partB = c->partB; a.strideB = c->strideB;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = c->update_desc; a.nt = init ? 0 : c->nt_mask;
     a.light = (!init && cfg.xfuse) ? 1 : 0;
+    if (resume_r0norm >= 0.0) { a.init = 2; a.r0norm_resume = resume_r0norm; a.s_in = c->sB; a.light = 0; }   // measure + re-arm, see k_update
     dim3 grid(c->grid_update), block(kBlock);
-    if (c->update_mode == 1 && !a.light) {
+    if (c->update_mode == 1 && !a.light && a.init != 2) {
         Update2DArgs<T> aa{};
         aa.g = c->g; aa.g.xlim = (int)round_up(c->g.N + 1, VEC); aa.wl = c->wl; aa.u = a;
 #define MI355CG_U2D(HASU, UNR, DESC) hipLaunchKernelGGL((k_update2d<T, VEC, HASU, UNR, DESC>), grid, block, 0, stream, aa)
@@ -523,18 +524,26 @@ int poll_summary(mi355cg_ctx* c, const IterCfg& cfg) {
 }
 
 // fp32 CG on (xf, rf): xf = 0 on entry, rf holds the right-hand side and ends as the recursive residual.
-int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volatile int* stop_flag, int* its, bool* interrupted) {
+// resume_r0norm < 0: fresh start (x = 0, p = 0).  resume_r0norm >= 0: residual replacement -- rf already holds the new true
+// residual; keep the direction and the CG scalars, restart only the correction vector xf and the reference norm.
+int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volatile int* stop_flag, int* its, bool* interrupted,
+                 double resume_r0norm = -1.0) {
     PlanSwap guard(c);
     const size_t bytes = sizeof(float) * c->storage_len;
     HIPCK(hipMemsetAsync(c->xf, 0, bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->pf[0], 0, bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->pf[1], 0, bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->apf, 0, bytes, c->stream));
-    c->cur = 0;
-    launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[0], c->apf, (const float*)nullptr, true, c->stream, own_partA(c));
+    int done_its = 0;
+    if (resume_r0norm < 0.0) {
+        HIPCK(hipMemsetAsync(c->pf[0], 0, bytes, c->stream));
+        HIPCK(hipMemsetAsync(c->pf[1], 0, bytes, c->stream));
+        HIPCK(hipMemsetAsync(c->apf, 0, bytes, c->stream));
+        c->cur = 0;
+        launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[0], c->apf, (const float*)nullptr, true, c->stream, own_partA(c));
+    } else {
+        done_its = c->summary_h->it;
+        launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[c->cur], c->apf, (const float*)nullptr, false, c->stream, own_partA(c), resume_r0norm);
+    }
     HIPCK(hipGetLastError());
     if (int rc = poll_summary(c, cfg)) return rc;
-    int done_its = 0;
     while (!c->summary_h->done) {
         if (stop_flag && *stop_flag) { *interrupted = true; break; }
         const int m = std::max(1, std::min(sync_every, cfg.rp.max_iterations - done_its));
@@ -569,6 +578,11 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
     const auto t0 = std::chrono::steady_clock::now();
     c->events.reset(); c->ev_pairs[0].clear(); c->ev_pairs[1].clear();
     const double inner_eps = prm->inner_eps > 0 ? prm->inner_eps : 1e-4;
+    // Restarted refinement is the default.  MI355CG_MIXED_RESTART=0 selects residual replacement (direction and CG scalars
+    // kept across outer steps): it saves iterations on small grids but stalled at 2e-5 on N = 8192 in round 1
+    // (profiles/r01_tune_notes.md), so it stays experimental and every stage is capped.
+    const bool restart = env_int("MI355CG_MIXED_RESTART", 1) != 0;
+    int stage_cap = 0;                       // replacement mode: iterations a later stage may spend (3x the first stage)
     const int sync_every = std::min(prm->sync_every > 0 ? prm->sync_every : 200, kHist);
     const int rgrid = 1024;
     auto residual_pass = [&](double* norm) -> int {      // rf = (float)(b - ap64), *norm = ||b - ap64||_2
@@ -591,19 +605,26 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
     bool interrupted = false, converged = bnorm == 0.0;
     while (!converged && total < prm->max_iterations && !interrupted) {
         mi355cg_params ip = *prm;
-        ip.eps_rel = inner_eps; ip.max_iterations = prm->max_iterations - total; ip.diagnostics = 0;
+        ip.eps_rel = inner_eps; ip.diagnostics = 0;
+        // residual replacement (default): the iteration counter runs on across outer steps, so the cap is the global one;
+        // restarted refinement (MI355CG_MIXED_RESTART=1): every inner solve starts from scratch with the remaining budget
+        ip.max_iterations = restart ? prm->max_iterations - total : prm->max_iterations;
+        if (!restart && stage_cap > 0) ip.max_iterations = std::min(ip.max_iterations, total + stage_cap);
         IterCfg cfg = make_cfg(&ip);
         cfg.xfuse = c->xfuse && c->update_mode == 0;
         int its = 0;
-        if (int rc = inner_cg_f32(c, cfg, sync_every, stop_flag, &its, &interrupted)) return rc;
-        total += its; ++outer;
+        const double resume = (!restart && outer > 0) ? rnorm : -1.0;
+        if (int rc = inner_cg_f32(c, cfg, sync_every, stop_flag, &its, &interrupted, resume)) return rc;
+        const int its_this = restart ? its : its - total;
+        total = restart ? total + its : its; ++outer;
+        if (!restart && stage_cap == 0) stage_cap = std::max(2000, 3 * its_this);
         hipLaunchKernelGGL(k_accumulate_f32, dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->x, c->xf);
         launch_apply<double, 2>(c, c->x, c->ap);
         const double prev = rnorm;
         if (int rc = residual_pass(&rnorm)) return rc;
         if (cb) cb(user, total, 0.0, rnorm, 0.0);
         converged = !prm->fixed_iterations && rnorm <= prm->eps_rel * bnorm;
-        if (prm->fixed_iterations || its == 0) break;
+        if (prm->fixed_iterations || its_this == 0) break;
         if (!converged && rnorm > 0.5 * prev) break;      // fp32 cannot improve this x any further
     }
     // leave the fp64 residual of the returned x in c->r for mi355cg_get_recursive_residual
