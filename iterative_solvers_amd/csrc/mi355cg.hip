@@ -835,6 +835,7 @@ int mi355cg_set_rhs(mi355cg_handle c, const double* b) {
 
 int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
     if (!c || !x_dev || !y_dev) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
     HIPCK(hipSetDevice(c->device));
     if (c->is_csr) {
         launch_csr_spmv(c, x_dev, y_dev, nullptr, nullptr, nullptr);
@@ -853,6 +854,7 @@ int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
 
 int mi355cg_apply(mi355cg_handle c, const double* x, double* y) {
     if (!c || !x || !y) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
     HIPCK(hipSetDevice(c->device));
     if (c->is_csr) {
         if (int rc = upload_packed<double>(c, x, c->p[1])) return rc;
@@ -885,6 +887,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
                   const volatile int* stop_flag, mi355cg_results* out) {
     if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
     if (prm->rule != MI355CG_RULE_MSG_MAXNORM && prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "unknown rule %d", prm->rule);
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
     HIPCK(hipSetDevice(c->device));
     if (c->is_csr) return solve_csr(c, prm, cb, user, stop_flag, out);
     if (c->dtype == MI355CG_F32_MIXED) return solve_mixed(c, prm, cb, user, stop_flag, out);
@@ -1057,6 +1060,7 @@ int mi355cg_get_recursive_residual(mi355cg_handle c, double* r) {
 }
 int mi355cg_get_true_residual(mi355cg_handle c, double* out) {
     if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
     if (!c->solved) return fail(MI355CG_ERR_STATE, "no solve has run on this handle");
     HIPCK(hipSetDevice(c->device));
     // residual = A x - b   (dirichlet_solver.cpp:147-161); scratch: A x in ap, difference in the inactive direction buffer

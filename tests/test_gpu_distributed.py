@@ -139,3 +139,19 @@ def test_bench_distributed_leg_runs_under_torchrun_with_rccl():
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["steps"] == 60 and j["value"] > 0 and j["scaling"] == "weak"
     assert "halo=gather" in j["config"]["parallelism"]
+
+
+def test_slab_handles_refuse_the_whole_grid_entry_points():
+    """apply / solve / true-residual on one slab would silently ignore the neighbours' rows: they must fail loudly."""
+    import ctypes as C
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd import _capi
+    from iterative_solvers_amd.distributed import SlabEngine
+    eng = SlabEngine(64, 1, 30, device=0)
+    lib = _capi.load()
+    buf = np.zeros(eng.packed_len)
+    assert lib.mi355cg_apply(eng._h, buf, buf.copy()) == _capi.ERR_STATE
+    res = _capi.Results()
+    p = isa.default_params(isa.RULE_REL_2NORM)
+    assert lib.mi355cg_solve(eng._h, C.byref(p), _capi.ITER_CB(), None, None, C.byref(res)) == _capi.ERR_STATE
+    assert b"mi355cg_dist_" in lib.mi355cg_last_error()
