@@ -100,6 +100,17 @@ int main() {
     timeit("write 2 streams grid=1024", 2.0 * N * 8, [&] { hipLaunchKernelGGL(wr2, dim3(1024), dim3(256), 0, 0, n, x, r, 0.0); });
     timeit("copy 1->1 grid=1024", 2.0 * N * 8, [&] { hipLaunchKernelGGL(cp1, dim3(1024), dim3(256), 0, 0, n, (const v2*)v[4], (v2*)v[5]); });
     timeit("copy 1->1 grid=2048", 2.0 * N * 8, [&] { hipLaunchKernelGGL(cp1, dim3(2048), dim3(256), 0, 0, n, (const v2*)v[4], (v2*)v[5]); });
+    // same six streams, bases staggered by odd multiples of 4 KiB + 256 B (do the streams collide on HBM channels?)
+    {
+        double* w[4]; const long long padB = 1 << 20;
+        for (auto& q2 : w) { CK(hipMalloc(&q2, N * 8 + padB)); CK(hipMemset(q2, 0, N * 8 + padB)); }
+        for (int stagger : {0, 256, 4352, 69888}) {
+            v2* xs = (v2*)((char*)w[0] + 0 * stagger); v2* rs = (v2*)((char*)w[1] + 1 * stagger);
+            v2* ps = (v2*)((char*)w[2] + 2 * stagger); v2* qs = (v2*)((char*)w[3] + 3 * stagger);
+            char nm[64]; snprintf(nm, 64, "update plain g=512 stagger=%d", stagger);
+            timeit(nm, B6, [&] { hipLaunchKernelGGL(upd<0>, dim3(512), dim3(256), 0, 0, n, xs, rs, ps, qs, 1e-3, part); });
+        }
+    }
     // big copy (well past the 256 MiB Infinity Cache): 2 x 813 MB
     double *A, *Bb; const long long M = 8 * N; CK(hipMalloc(&A, M * 8)); CK(hipMalloc(&Bb, M * 8)); CK(hipMemset(A, 0, M * 8));
     timeit("copy 813MB->813MB grid=2048", 2.0 * M * 8, [&] { hipLaunchKernelGGL(cp1, dim3(2048), dim3(256), 0, 0, M / 2, (const v2*)A, (v2*)Bb); });

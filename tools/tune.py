@@ -52,6 +52,5 @@ def ab(configs, rounds=5):
 
 
 if __name__ == "__main__":
-    base = {"MI355CG_XFUSE": 1, "MI355CG_XDEPTH": 2, "MI355CG_STENCIL_WAVES": 4096, "MI355CG_UPDATE_BLOCKS": 512, "MI355CG_UPDATE_DESC": 1}
-    ab([base, {**base, "MI355CG_UPDATE_BLOCKS": 256}, {**base, "MI355CG_XDEPTH": 4, "MI355CG_STENCIL_WAVES": 3072},
-        {**base, "MI355CG_UPDATE_DESC": 0}, {**base, "MI355CG_XFUSE": 0}], rounds=7)
+    base = {"MI355CG_STAGGER": 4352}
+    ab([base, {"MI355CG_STAGGER": 0}, {"MI355CG_STAGGER": 256}, {"MI355CG_STAGGER": 69888}, {"MI355CG_STAGGER": 1280}], rounds=7)
