@@ -38,6 +38,23 @@ __global__ __launch_bounds__(256) void upd_unroll(long long n, v2* x, v2* r, con
     }
     if (s == 12345.678) part[blockIdx.x] = s;
 }
+// the 3-stream light update (r -= alpha*q, sum r^2), 4 groups in flight, optional reverse sweep
+template <bool REV>
+__global__ __launch_bounds__(256) void upd_light(long long n, v2* __restrict__ r, const v2* __restrict__ q, double alpha, double* part) {
+    const long long stride = (long long)gridDim.x * 256;
+    double s = 0;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        v2 r0[4], qv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { long long j = i + k * stride; if (REV) j = n - 1 - j; r0[k] = r[j]; qv[k] = q[j]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { long long j = i + k * stride; if (REV) j = n - 1 - j; v2 rn = r0[k] - alpha * qv[k]; s += rn.x * rn.x + rn.y * rn.y; r[j] = rn; }
+    }
+    for (; i < n; i += stride) { long long j = REV ? n - 1 - i : i; v2 rn = r[j] - alpha * q[j]; s += rn.x * rn.x + rn.y * rn.y; r[j] = rn; }
+    if (s == 12345.678) part[blockIdx.x] = s;
+}
 // each block owns a contiguous segment
 __global__ __launch_bounds__(256) void upd_seg(long long n, v2* x, v2* r, const v2* p, const v2* q, double alpha, double* part) {
     const long long per = (n + gridDim.x - 1) / gridDim.x, b = (long long)blockIdx.x * per, e = b + per < n ? b + per : n;
@@ -96,6 +113,12 @@ int main() {
     timeit("update unroll1 grid=4096", B6, [&] { hipLaunchKernelGGL(upd_unroll<1>, dim3(4096), dim3(256), 0, 0, n, x, r, p, q, 1e-3, part); });
     timeit("update segmented grid=512", B6, [&] { hipLaunchKernelGGL(upd_seg, dim3(512), dim3(256), 0, 0, n, x, r, p, q, 1e-3, part); });
     timeit("update segmented grid=2048", B6, [&] { hipLaunchKernelGGL(upd_seg, dim3(2048), dim3(256), 0, 0, n, x, r, p, q, 1e-3, part); });
+    for (int g : {256, 512, 1024}) {
+        char nm[64]; snprintf(nm, 64, "light 2R1W fwd grid=%d", g);
+        timeit(nm, 3.0 * N * 8, [&] { hipLaunchKernelGGL(upd_light<false>, dim3(g), dim3(256), 0, 0, n, r, q, 1e-3, part); });
+        snprintf(nm, 64, "light 2R1W rev grid=%d", g);
+        timeit(nm, 3.0 * N * 8, [&] { hipLaunchKernelGGL(upd_light<true>, dim3(g), dim3(256), 0, 0, n, r, q, 1e-3, part); });
+    }
     timeit("read 4 streams grid=1024", 4.0 * N * 8, [&] { hipLaunchKernelGGL(rd4, dim3(1024), dim3(256), 0, 0, n, x, r, p, q, part); });
     timeit("write 2 streams grid=1024", 2.0 * N * 8, [&] { hipLaunchKernelGGL(wr2, dim3(1024), dim3(256), 0, 0, n, x, r, 0.0); });
     timeit("copy 1->1 grid=1024", 2.0 * N * 8, [&] { hipLaunchKernelGGL(cp1, dim3(1024), dim3(256), 0, 0, n, (const v2*)v[4], (v2*)v[5]); });
