@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid intervals per side on one GPU")
     ap.add_argument("--rule", choices=["rel2", "msg"], default="rel2")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f32 = BASELINE config 3: the fp32-storage inner CG of the mixed-precision path (use --grid 8192)")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     args = ap.parse_args()
@@ -110,7 +112,9 @@ def main():
 
     n = args.n
     U = unknowns(n)
-    sysm = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=local_rank)
+    f32 = args.dtype == "f32"
+    wbytes = 4.0 if f32 else 8.0
+    sysm = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=local_rank, dtype=isa.F32_MIXED if f32 else isa.F64)
     h = sysm._handle
 
     def run(iters: int, profile: bool):
@@ -142,7 +146,7 @@ def main():
         t = {name: h.kernel_time(i) for i, name in enumerate(("stencil", "update"))}
         dom = max(t, key=lambda name: t[name][0] * t[name][1])
         ms, launches = t[dom]
-        alg = KERNEL_ALG_WORDS[dom] * 8.0 * U
+        alg = KERNEL_ALG_WORDS[dom] * wbytes * U
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         tr = read_traffic()
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -150,20 +154,20 @@ def main():
                     "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
                     "alg_bytes_per_launch": alg, "alg_words_per_unknown": KERNEL_ALG_WORDS[dom],
                     "other": {name: {"avg_ms": round(t[name][0], 5),
-                                     "achieved": round(KERNEL_ALG_WORDS[name] * 8.0 * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}
+                                     "achieved": round(KERNEL_ALG_WORDS[name] * wbytes * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}
                               for name in t}}
 
     out = {
         "metric": "cg_iters_per_sec", "value": round(its, 2), "unit": "iters/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson fp64, matrix-free CG, fixed {args.steps} iterations",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson {'fp32 inner CG of the mixed-precision path' if f32 else 'fp64'}, matrix-free CG, fixed {args.steps} iterations",
                    "n": n, "unknowns": U, "rule": args.rule, "layout": h.layout()},
-        "hbm_gbps": round(ALG_BYTES_PER_UNKNOWN * U * its / 1e9, 1),
-        "hbm_frac_of_8TBps": round(ALG_BYTES_PER_UNKNOWN * U * its / 1e9 / HBM_PEAK_GBPS, 4),
+        "hbm_gbps": round(ALG_BYTES_PER_UNKNOWN * (wbytes / 8.0) * U * its / 1e9, 1),
+        "hbm_frac_of_8TBps": round(ALG_BYTES_PER_UNKNOWN * (wbytes / 8.0) * U * its / 1e9 / HBM_PEAK_GBPS, 4),
         "roofline": roofline,
     }
-    if args.cpu_iters > 0:
+    if args.cpu_iters > 0 and not f32:
         out["cpu_baseline"] = cpu_baseline(n, args.cpu_iters)
     print(json.dumps(out))
 
