@@ -173,7 +173,9 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     const long long strip_rows = add_panels(g, vec, g.y_lo, g.y_hi, 0, dry);
     const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 4096));
     int ty = (int)((strip_rows + target_waves - 1) / target_waves);
-    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), std::min(ty, 512));
+    // enough items to fill the chip, but never taller than MAX_ROWS: beyond N = 4096 several rounds of 24-row items beat
+    // one round of taller ones (+5 % at N = 8192, profiles/r01_tune_notes.md)
+    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), std::min(ty, env_int("MI355CG_MAX_ROWS", 24)));
     if (env_int("MI355CG_ROWS", 0) > 0) ty = env_int("MI355CG_ROWS", 0);
     c->rows_per_item = ty;
     c->wl = WorkList{};

@@ -52,5 +52,4 @@ def ab(configs, rounds=5):
 
 
 if __name__ == "__main__":
-    base = {"MI355CG_STAGGER": 4352}
-    ab([base, {"MI355CG_STAGGER": 0}, {"MI355CG_STAGGER": 256}, {"MI355CG_STAGGER": 69888}, {"MI355CG_STAGGER": 1280}], rounds=7)
+    ab([{"MI355CG_MAX_ROWS": 24}, {"MI355CG_MAX_ROWS": 16}, {"MI355CG_MAX_ROWS": 32}, {"MI355CG_MAX_ROWS": 48}, {"MI355CG_MAX_ROWS": 512}], rounds=3)
