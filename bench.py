@@ -150,7 +150,7 @@ def main():
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         tr = read_traffic()
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_6290": round(achieved / 6290.0, 4),
                     "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
                     "alg_bytes_per_launch": alg, "alg_words_per_unknown": KERNEL_ALG_WORDS[dom],
                     "other": {name: {"avg_ms": round(t[name][0], 5),
