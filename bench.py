@@ -27,9 +27,12 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured-achievable
 ALG_BYTES_PER_UNKNOWN = 88.0    # 11 words fp64 per unknown per iteration
-# compulsory words per unknown and launch.  Default REL_2NORM path: the stencil launch also
-# carries the previous x update (read r,p,x / write p,Ap,x = 6), the update launch is r -= alpha*Ap (read r,Ap / write r = 3).
-# MSG rule or MI355CG_XFUSE=0: stencil 4 (read r,p / write p,Ap), update 6 (read x,p,r,Ap / write x,r).
+# Compulsory words per unknown and launch of THIS implementation -- what roofline.achieved counts.
+# Default (A p recomputed in the update launch, never stored): REL_2NORM stencil launch = read r,p,x / write p,x = 5,
+# update launch = read p,r / write r = 3 (8 per iteration); MSG: stencil read r,p / write p = 3, update read p,r,x / write r,x = 5.
+# MI355CG_RECOMPUTE=0: REL_2NORM 6 + 3 (A p stored and streamed back), MSG or MI355CG_XFUSE=0: 4 + 6.
+KERNEL_ALG_WORDS_RECOMP = {"stencil": 5, "update": 3}
+KERNEL_ALG_WORDS_RECOMP_MSG = {"stencil": 3, "update": 5}
 KERNEL_ALG_WORDS_XFUSE = {"stencil": 6, "update": 3}
 KERNEL_ALG_WORDS_PLAIN = {"stencil": 4, "update": 6}
 
@@ -142,7 +145,12 @@ def main():
         k = min(args.steps, 500)
         run(k, True)
         xfuse = args.rule == "rel2" and os.environ.get("MI355CG_XFUSE", "1") != "0"
-        KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_XFUSE if xfuse else KERNEL_ALG_WORDS_PLAIN
+        recomp = os.environ.get("MI355CG_RECOMPUTE", "1") != "0" and (xfuse or args.rule == "msg")
+        if recomp:
+            KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_RECOMP if xfuse else KERNEL_ALG_WORDS_RECOMP_MSG
+        else:
+            KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_XFUSE if xfuse else KERNEL_ALG_WORDS_PLAIN
+        words_iter = sum(KERNEL_ALG_WORDS.values())
         t = {name: h.kernel_time(i) for i, name in enumerate(("stencil", "update"))}
         dom = max(t, key=lambda name: t[name][0] * t[name][1])
         ms, launches = t[dom]
@@ -153,6 +161,9 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_6290": round(achieved / 6290.0, 4),
                     "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
                     "alg_bytes_per_launch": alg, "alg_words_per_unknown": KERNEL_ALG_WORDS[dom],
+                    # what the whole iteration really has to move in this implementation, and the rate that is
+                    "words_per_unknown_per_iteration": words_iter,
+                    "moved_gbps_per_iteration": round(words_iter * wbytes * U * its / 1e9, 1),
                     "other": {name: {"avg_ms": round(t[name][0], 5),
                                      "achieved": round(KERNEL_ALG_WORDS[name] * wbytes * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}
                               for name in t}}

@@ -162,7 +162,13 @@ int  mi355cg_dist_scatter_ghosts(mi355cg_handle h, int vector /*0 r, 1 current d
 int  mi355cg_dist_stencil(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride,
                           int rows /*0 all, 1 interior, 2 edge rows*/, void *stream);
 int  mi355cg_dist_flip(mi355cg_handle h);          /* once per stencil phase: new direction becomes current */
-int  mi355cg_dist_update(mi355cg_handle h, const double *gathered_stencil_sums, int nranks, int estride, void *stream);
+/* rows as in mi355cg_dist_stencil.  When mi355cg_dist_update_reads_ghosts() is non-zero (the default 8-word
+ * iteration: the update rebuilds A p from the stored direction instead of streaming it) the edge rows read the
+ * direction's ghost rows, so those must have arrived before rows 0 / 2 run; otherwise rows 0 / 1 run the flat
+ * update over the whole slab and rows 2 is a no-op.                                                          */
+int  mi355cg_dist_update(mi355cg_handle h, const double *gathered_stencil_sums, int nranks, int estride,
+                         int rows /*0 all, 1 interior, 2 edge rows*/, void *stream);
+int  mi355cg_dist_update_reads_ghosts(mi355cg_handle h);   /* valid after mi355cg_dist_begin */
 int  mi355cg_dist_check(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride, void *stream);
 int  mi355cg_dist_summary(mi355cg_handle h, mi355cg_results *out, int *done);   /* after a stream sync */
 int  mi355cg_dist_finish(mi355cg_handle h, void *stream);   /* once after the loop: flush the pending x update */

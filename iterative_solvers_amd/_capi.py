@@ -22,7 +22,7 @@ EXPORTS = [
     "mi355cg_set_profiling", "mi355cg_get_kernel_time", "mi355cg_get_layout",
     "mi355cg_slab_rows", "mi355cg_create_slab", "mi355cg_owned_range", "mi355cg_dist_begin",
     "mi355cg_dist_reduce", "mi355cg_dist_sums_ptr", "mi355cg_dist_record_layout", "mi355cg_dist_scatter_ghosts", "mi355cg_dist_stencil", "mi355cg_dist_flip",
-    "mi355cg_dist_update", "mi355cg_dist_check", "mi355cg_dist_summary", "mi355cg_dist_finish", "mi355cg_dist_history",
+    "mi355cg_dist_update", "mi355cg_dist_update_reads_ghosts", "mi355cg_dist_check", "mi355cg_dist_summary", "mi355cg_dist_finish", "mi355cg_dist_history",
     "mi355cg_dist_halo", "mi355cg_dist_halo_recv_counts",
 ]
 
@@ -107,7 +107,8 @@ def load():
     L.mi355cg_dist_scatter_ghosts.argtypes = [H, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_stencil.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_flip.argtypes = [H]
-    L.mi355cg_dist_update.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.mi355cg_dist_update.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.mi355cg_dist_update_reads_ghosts.argtypes = [H]
     L.mi355cg_dist_check.argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.mi355cg_dist_summary.argtypes = [H, C.POINTER(Results), IP]
     L.mi355cg_dist_finish.argtypes = [H, C.c_void_p]

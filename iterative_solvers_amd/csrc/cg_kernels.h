@@ -275,7 +275,9 @@ __device__ inline Item decode_item(const WorkList& wl, int item) {
 // along here -- p_{k-1} is this kernel's input direction and is in registers anyway -- so the update kernel
 // shrinks to r -= alpha*Ap (3 words) and an iteration moves 9 words per unknown instead of 10.  Element-wise
 // arithmetic and order are unchanged; the last pending x update is flushed by k_flush_x after the loop.
-template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool DESC, bool XUPD = false>
+// NOAP: A p is only reduced into (Ap, p), not stored -- the update phase recomputes it from the stored direction
+// (k_update_st), which removes one written and one read word per unknown and iteration.
+template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool DESC, bool XUPD = false, bool NOAP = false>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     typedef typename VecOf<T, VEC>::type vec_t;
     __shared__ double lds[2 * kWaves];
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                     {   // branch-free stores: lanes outside the stored columns write the trash block
                         const bool sv = xin && x >= cmin;
                         const long long off = row_off(g, y) - g.base0 + x;
-                        *reinterpret_cast<vec_t*>(sv ? a.ap + off : a.trash) = out;
+                        if (!NOAP) *reinterpret_cast<vec_t*>(sv ? a.ap + off : a.trash) = out;
                         if (FUSED) *reinterpret_cast<vec_t*>(sv ? a.pout + off : a.trash) = pn_c;
                         if (XUPD) {
                             vec_t xn;
@@ -563,6 +565,169 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
         if (blockIdx.x == 0) {
             CgState o = s;
             if (!a.init) { o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz; }
+            *a.s_out = o;
+        }
+    }
+}
+
+// ---- phase B, recomputing variant: r -= alpha * (A_h p) with A_h p rebuilt from the stored direction -----------
+// The flat update streams A p back in (one word per unknown) after the stencil launch streamed it out (another
+// word).  This kernel walks the same (chunk, strip) items as the stencil, keeps three rows of p in registers and
+// evaluates the 5-point formula again -- same operands, same operation order, hence the same bits as the values
+// the stencil launch reduced into (Ap, p) -- so A p never touches HBM.  An iteration moves 8 words per unknown
+// (stencil launch: r, p_old, x in; p, x out; this launch: p, r in; r out) instead of 9 (REL_2NORM) or 10 (MSG).
+// FULL adds the x update and the MSG norms (|dx|, |x - u|), element-wise identical to k_update.
+template <typename T>
+struct UpdateStArgs {
+    Geom g;
+    WorkList wl;
+    const T* p;          // current direction, ghost rows valid
+    T* r; T* x; const T* u;
+    const T* zero; T* trash;
+    const double* partA; int nA, strideA, esA;
+    double* partB; int strideB, slotB;
+    const CgState* s_in; CgState* s_out;
+    int rule;
+    int reverse;         // take the items from the last to the first (start where the stencil launch ended)
+};
+
+template <typename T, int VEC, bool FULL, bool HAS_U, int DEPTH, bool DESC>
+__global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
+    typedef typename VecOf<T, VEC>::type vec_t;
+    __shared__ double lds[2 * kWaves];
+    const Geom& g = a.g;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+
+    const CgState s = *a.s_in;
+    if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+    double alpha_d, rz = 0.0;
+    {
+        const double pap = dd_value(reduce_parts_dd(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
+        if (a.rule == 0) {
+            rz = dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
+            alpha_d = rz / pap;                       // msg_solver.cpp:102
+        } else {
+            alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
+        }
+    }
+    const T alpha = (T)alpha_d;
+    const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
+    dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
+    double s_rmax = 0, s_dmax = 0, s_emax = 0;
+    constexpr int DIR = DESC ? -1 : 1;
+
+    struct Raw { vec_t p, r, x, u; T pe; };
+
+    for (int idx = blockIdx.x * kWaves + wave; idx < a.wl.nitems; idx += gridDim.x * kWaves) {
+        const Item it = decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx);
+        const int x = it.strip * (kWave * VEC) + lane * VEC;
+        const bool xin = x < g.xlim;
+        const bool edge = (lane == 0) || (lane == kWave - 1);
+        const int xe = lane == 0 ? x - 1 : x + VEC;
+        const int nrows = it.yb - it.ya + 1;
+        const int ystart = DESC ? it.yb : it.ya;
+
+        // branch-free loads, as in k_stencil.  `own`: the row is one of this item's rows (its r / x / u are needed).
+        auto fetch = [&](int y, bool own, bool row_ok) -> Raw {
+            Raw w;
+            const int cmin = y <= g.half ? g.cb : 0;
+            const long long off = row_off(g, y) - g.base0;
+            const bool v = row_ok && xin && x >= cmin;
+            w.p = *reinterpret_cast<const vec_t*>(v ? a.p + off + x : a.zero);
+            const bool vo = v && own;
+            w.r = *reinterpret_cast<const vec_t*>(vo ? a.r + off + x : a.zero);
+            if (FULL) w.x = *reinterpret_cast<const vec_t*>(vo ? a.x + off + x : a.zero);
+            if (FULL && HAS_U) w.u = *reinterpret_cast<const vec_t*>(vo ? a.u + off + x : a.zero);
+            const bool ev = row_ok && own && edge && xe >= cmin && xe < g.xlim;
+            w.pe = *(ev ? a.p + off + xe : a.zero);
+            return w;
+        };
+
+        Raw q[DEPTH];
+        vec_t p_b, p_a;
+        Raw c;                             // centre row
+        {
+            const Raw wb = fetch(ystart - DIR, false, true);
+            c = fetch(ystart, true, true);
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) q[k] = fetch(ystart + DIR * (k + 1), k + 1 < nrows, k + 1 <= nrows);
+            p_b = wb.p;
+        }
+        for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                const int i = i0 + k;
+                if (i < nrows) {
+                    const int y = ystart + DIR * i;
+                    const Raw w = q[k];
+                    q[k] = fetch(ystart + DIR * (i + 1 + DEPTH), i + 1 + DEPTH < nrows, i + 1 + DEPTH <= nrows);
+                    p_a = w.p;
+
+                    T left0 = __shfl_up(c.p[VEC - 1], 1, kWave);
+                    T rightL = __shfl_down(c.p[0], 1, kWave);
+                    if (lane == 0) left0 = c.pe;
+                    if (lane == kWave - 1) rightL = c.pe;
+
+                    const int cmin = y <= g.half ? g.cb : 0;
+                    const int xint0 = y <= g.half ? g.half + 1 : 1;
+                    const vec_t& top = DESC ? p_b : p_a;
+                    const vec_t& bot = DESC ? p_a : p_b;
+                    vec_t rn, xn;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const T cc = c.p[j];
+                        const T L = j == 0 ? left0 : c.p[j - 1];
+                        const T R = j == VEC - 1 ? rightL : c.p[j + 1];
+                        T v = cA * cc;                                   // the stencil launch's formula, verbatim
+                        v = v + cxk * L;
+                        v = v + cxk * R;
+                        v = v + cyk * top[j];
+                        v = v + cyk * bot[j];
+                        const int xj = x + j;
+                        const T apj = (xj >= xint0 && xj <= g.N - 1) ? v : (T)0;
+                        rn[j] = c.r[j] - alpha * apj;                    // r = r - alpha*A_z      msg_solver.cpp:110-112
+                        const double rd = (double)rn[j];
+                        dd_acc_prod(s_rr, rd, rd);
+                        s_rmax = fmax(s_rmax, fabs(rd));
+                        if (FULL) {
+                            xn[j] = c.x[j] + alpha * cc;                 // x = x + alpha*z        msg_solver.cpp:105-107
+                            const double dx = (double)(xn[j] - c.x[j]);  // diff = x - x_prev      msg_solver.cpp:124-127
+                            s_dmax = fmax(s_dmax, fabs(dx));
+                            dd_acc_prod(s_d2, dx, dx);
+                            if (HAS_U) {
+                                const double ee = (double)(xn[j] - c.u[j]);   // error = x - u     msg_solver.cpp:132-136
+                                s_emax = fmax(s_emax, fabs(ee));
+                                dd_acc_prod(s_e2, ee, ee);
+                            }
+                        }
+                    }
+                    {
+                        const bool sv = xin && x >= cmin;
+                        const long long off = row_off(g, y) - g.base0 + x;
+                        *reinterpret_cast<vec_t*>(sv ? a.r + off : a.trash) = rn;
+                        if (FULL) *reinterpret_cast<vec_t*>(sv ? a.x + off : a.trash) = xn;
+                    }
+                    p_b = c.p; c = w;
+                }
+            }
+        }
+    }
+
+    const dd t_rr = block_reduce_dd(s_rr, lds);
+    const double t_rmax = block_reduce<true>(s_rmax, lds);
+    double t_dmax = 0, t_emax = 0; dd t_d2 = dd_zero(), t_e2 = dd_zero();
+    if (FULL) { t_dmax = block_reduce<true>(s_dmax, lds); t_d2 = block_reduce_dd(s_d2, lds); }
+    if (FULL && HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce_dd(s_e2, lds); }
+    if (threadIdx.x == 0) {
+        const int b = a.slotB + blockIdx.x, st = a.strideB;
+        a.partB[FB_RR * st + b] = t_rr.hi; a.partB[(FB_RR + FB_LO) * st + b] = t_rr.lo;
+        a.partB[FB_D2 * st + b] = t_d2.hi; a.partB[(FB_D2 + FB_LO) * st + b] = t_d2.lo;
+        a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
+        a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
+        if (blockIdx.x == 0) {
+            CgState o = s;
+            o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz;
             *a.s_out = o;
         }
     }

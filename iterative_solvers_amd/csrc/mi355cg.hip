@@ -71,6 +71,8 @@ struct mi355cg_ctx {
     int update_mode = 1, stencil_desc = 1, update_desc = 0, update_unroll = 4;   // launch-shape knobs (env)
     int nt_mask = 0;                    // cache-policy bits (NT_*), env MI355CG_NT
     int xfuse = 1, xdepth = 2;          // REL_2NORM: fold the x update into the next stencil launch (env MI355CG_XFUSE, MI355CG_XDEPTH)
+    int recompute = 1, udepth = 4, udepth_full = 2;      // update phase rebuilds A p from the stored direction instead of streaming it (env MI355CG_RECOMPUTE, MI355CG_UDEPTH)
+    int nB_own = 0;                     // partB slots written by the last update-phase launch(es) of this context
     int strideA = 0, strideB = 0;
     struct Plan { WorkList wl; int grid_stencil = 0, grid_update = 0, rows_per_item = 0; } plan32;   // fp32 kernels (VEC = 4)
 
@@ -202,6 +204,10 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     c->xfuse = env_int("MI355CG_XFUSE", 1);
     c->xdepth = env_int("MI355CG_XDEPTH", 2);
     c->use_graph = env_int("MI355CG_GRAPH", -1);
+    c->recompute = env_int("MI355CG_RECOMPUTE", 1);
+    c->udepth = env_int("MI355CG_UDEPTH", 4);
+    c->udepth_full = env_int("MI355CG_UDEPTH_FULL", 2);
+    c->nB_own = c->grid_update;
 }
 
 PackGeom pack_geom(const mi355cg_ctx* c) {
@@ -232,13 +238,13 @@ void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a, const S
     else launch_stencil_dir<T, VEC, FUSED, MSG, false>(c, a, w);
 }
 // fused stencil that also applies the previous iteration's x update (REL_2NORM fast path)
-template <typename T, int VEC>
+template <typename T, int VEC, bool NOAP>
 void launch_stencil_xupd(const mi355cg_ctx* c, const StencilArgs<T>& a, const StencilWhere& w) {
     dim3 grid(w.grid), block(kBlock);
     // 2 rows in flight: with the extra x stream 4 rows need 138 VGPRs (3 waves/SIMD, the 4096-wave grid no
     // longer fits at once); 2 rows need 104 (4 waves/SIMD) and measured 5 % faster (profiles/r01_tune_notes.md)
-    if (c->xdepth == 4) hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 4, false, true>), grid, block, 0, w.stream, a);
-    else hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 2, false, true>), grid, block, 0, w.stream, a);
+    if (c->xdepth == 4) hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 4, false, true, NOAP>), grid, block, 0, w.stream, a);
+    else hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 2, false, true, NOAP>), grid, block, 0, w.stream, a);
 }
 
 template <typename T, int VEC>
@@ -260,7 +266,7 @@ void launch_apply(const mi355cg_ctx* c, const T* v, T* out) {
     launch_stencil_depth<T, VEC, false, false>(c, a, w);
 }
 
-struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool xfuse = false; };
+struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool xfuse = false; bool recomp = false; };
 
 // Phase A'.  Does NOT flip c->cur (a slab's interior and edge launches share one direction pair).
 template <typename T, int VEC>
@@ -271,16 +277,45 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
     a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
     a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slotA;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
-    if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a, w);
-    else if (cfg.xfuse) { a.x = x; launch_stencil_xupd<T, VEC>(c, a, w); }
+    if (cfg.recomp && cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) {        // A p is not stored: the update launch recomputes it
+        dim3 grid(w.grid), block(kBlock);
+        if (c->depth == 2) hipLaunchKernelGGL((k_stencil<T, VEC, true, true, 2, false, false, true>), grid, block, 0, w.stream, a);
+        else hipLaunchKernelGGL((k_stencil<T, VEC, true, true, 4, false, false, true>), grid, block, 0, w.stream, a);
+    }
+    else if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a, w);
+    else if (cfg.xfuse && cfg.recomp) { a.x = x; launch_stencil_xupd<T, VEC, true>(c, a, w); }
+    else if (cfg.xfuse) { a.x = x; launch_stencil_xupd<T, VEC, false>(c, a, w); }
     else launch_stencil_depth<T, VEC, true, false>(c, a, w);
 }
-PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, c->grid_update, c->strideB, 1}; }
+PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, c->nB_own, c->strideB, 1}; }
 PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, c->grid_stencil, c->strideA, 1}; }
 
 template <typename T, int VEC>
 void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, bool init,
-                   hipStream_t stream, const PartSrc& pa, double resume_r0norm = -1.0) {
+                   hipStream_t stream, const PartSrc& pa, double resume_r0norm = -1.0, const StencilWhere* where = nullptr) {
+    if (cfg.recomp && !init && resume_r0norm < 0.0) {
+        // recomputing update on the stencil's work items, marched the other way (it starts on what the stencil touched last)
+        const StencilWhere w = where ? *where : StencilWhere{stream, &c->wl, c->grid_stencil, 0};
+        UpdateStArgs<T> a{};
+        a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC); a.wl = *w.wl;
+        a.p = p; a.r = r; a.x = x; a.u = u;
+        a.zero = reinterpret_cast<const T*>(c->zero_blk); a.trash = reinterpret_cast<T*>(c->trash_blk);
+        a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
+        a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slotA;
+        a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = c->update_desc;
+        dim3 grid(w.grid), block(kBlock);
+        const int ud = cfg.xfuse ? c->udepth : c->udepth_full;     // rows in flight: the FULL variants carry x (and u) too
+#define MI355CG_UST(FULL, HASU) do { \
+        if (c->update_desc) { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 2, true>), grid, block, 0, w.stream, a); \
+                              else hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 4, true>), grid, block, 0, w.stream, a); } \
+        else                { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 2, false>), grid, block, 0, w.stream, a); \
+                              else hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 4, false>), grid, block, 0, w.stream, a); } } while (0)
+        if (cfg.xfuse) MI355CG_UST(false, false);
+        else if (cfg.has_u) MI355CG_UST(true, true);
+        else MI355CG_UST(true, false);
+#undef MI355CG_UST
+        return;
+    }
     UpdateArgs<T> a{};
     a.begin = c->g.own_begin / VEC; a.nvec = c->g.own_len / VEC;
     a.x = x; a.r = r; a.p = p; a.ap = ap; a.u = u;
@@ -289,7 +324,7 @@ void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, c
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = c->update_desc; a.nt = init ? 0 : c->nt_mask;
     a.light = (!init && cfg.xfuse) ? 1 : 0;
     if (resume_r0norm >= 0.0) { a.init = 2; a.r0norm_resume = resume_r0norm; a.s_in = c->sB; a.light = 0; }   // measure + re-arm, see k_update
-    dim3 grid(c->grid_update), block(kBlock);
+    dim3 grid(c->update_mode == 1 ? c->grid_update : c->nB_own), block(kBlock);
     if (c->update_mode == 1 && !a.light && a.init != 2) {
         Update2DArgs<T> aa{};
         aa.g = c->g; aa.g.xlim = (int)round_up(c->g.N + 1, VEC); aa.wl = c->wl; aa.u = a;
@@ -531,6 +566,7 @@ int poll_summary(mi355cg_ctx* c, const IterCfg& cfg) {
 int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volatile int* stop_flag, int* its, bool* interrupted,
                  double resume_r0norm = -1.0) {
     PlanSwap guard(c);
+    c->nB_own = cfg.recomp ? c->grid_stencil : c->grid_update;
     const size_t bytes = sizeof(float) * c->storage_len;
     HIPCK(hipMemsetAsync(c->xf, 0, bytes, c->stream));
     int done_its = 0;
@@ -614,6 +650,7 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
         if (!restart && stage_cap > 0) ip.max_iterations = std::min(ip.max_iterations, total + stage_cap);
         IterCfg cfg = make_cfg(&ip);
         cfg.xfuse = c->xfuse && c->update_mode == 0;
+        cfg.recomp = c->recompute && cfg.xfuse;
         int its = 0;
         const double resume = (!restart && outer > 0) ? rnorm : -1.0;
         if (int rc = inner_cg_f32(c, cfg, sync_every, stop_flag, &its, &interrupted, resume)) return rc;
@@ -681,7 +718,7 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     }
     build_worklist(c, vec);
     c->strideA = std::max({c->grid_stencil, c->grid_int + c->grid_edge, c->plan32.grid_stencil});
-    c->strideB = std::max(c->grid_update, c->plan32.grid_update);
+    c->strideB = std::max({c->grid_update, c->plan32.grid_update, c->strideA});   // the recomputing update runs on the stencil's grids
 
     int rc = MI355CG_OK;
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
@@ -752,7 +789,7 @@ int mi355cg_create_csr(long long nrows, const int* row_map, const int* entries, 
     c->grid_csr = (int)std::max<long long>(1, std::min<long long>(2048, nblk));
     c->grid_update = (int)std::max<long long>(1, std::min<long long>(512, nblk));
     c->grid_stencil = c->grid_csr;
-    c->strideA = c->grid_csr; c->strideB = c->grid_update;
+    c->strideA = c->grid_csr; c->strideB = c->grid_update; c->nB_own = c->grid_update;
     c->update_mode = 0;
     int rc = MI355CG_OK;
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
@@ -896,7 +933,9 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
     IterCfg cfg = make_cfg(prm);
     const bool diag = cfg.want_diag != 0;
-    cfg.xfuse = c->xfuse && !msg && !diag && !cfg.has_u && c->update_mode == 0;     // 9-word iteration
+    cfg.xfuse = c->xfuse && !msg && !diag && !cfg.has_u && c->update_mode == 0;     // x update rides in the stencil launch
+    cfg.recomp = c->recompute && c->update_mode == 0 && (cfg.xfuse || msg);        // 8-word iteration: A p is never stored
+    c->nB_own = cfg.recomp ? c->grid_stencil : c->grid_update;
     if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
 
     const auto t0 = std::chrono::steady_clock::now();
@@ -1136,6 +1175,7 @@ static hipStream_t pick_stream(mi355cg_ctx*, void* stream) { return (hipStream_t
 static IterCfg dist_cfg(const mi355cg_ctx* c) {
     IterCfg cfg = make_cfg(&c->dist_prm);
     cfg.xfuse = c->xfuse && c->update_mode == 0 && c->dist_prm.rule == MI355CG_RULE_REL_2NORM && !cfg.has_u;
+    cfg.recomp = c->recompute && c->update_mode == 0 && (cfg.xfuse || c->dist_prm.rule == MI355CG_RULE_MSG_MAXNORM);
     return cfg;
 }
 
@@ -1155,6 +1195,7 @@ int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream
     HIPCK(hipMemsetAsync(c->ap, 0, bytes, st));
     HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, st));
     c->cur = 0;
+    c->nB_own = cfg.recomp ? c->grid_stencil : c->grid_update;
     launch_update<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, /*init=*/true, st, own_partA(c));
     HIPCK(hipGetLastError());
     c->solved = true;
@@ -1173,7 +1214,7 @@ int mi355cg_dist_reduce(mi355cg_handle c, int which, int with_rows, void* stream
     RecordArgs a{};
     a.rec = which == 0 ? c->sumsA : c->sumsB; a.header = kRecHeader; a.row_slot = g.Pu;
     if (which == 0) { a.part = c->partA; a.n = c->nA_dist; a.stride = c->strideA; a.nsum = kNumSumsA; a.lo_off = FA_LO; a.max_first = 0; a.nmax = 0; }
-    else { a.part = c->partB; a.n = c->grid_update; a.stride = c->strideB; a.nsum = kNumSumsB; a.lo_off = FB_LO; a.max_first = FB_RMAX; a.nmax = 3; }
+    else { a.part = c->partB; a.n = c->nB_own; a.stride = c->strideB; a.nsum = kNumSumsB; a.lo_off = FB_LO; a.max_first = FB_RMAX; a.nmax = 3; }
     if (with_rows) {
         a.v = which == 0 ? c->p[c->cur] : c->r;
         a.off_lo = phys_start(g, g.y_lo) - g.base0; a.len_lo = g.y_lo <= g.half ? g.Pb : g.Pu;
@@ -1242,13 +1283,30 @@ int mi355cg_dist_flip(mi355cg_handle c) {
     c->cur ^= 1;
     return MI355CG_OK;
 }
-int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, int estride, void* stream) {
+// rows: as in mi355cg_dist_stencil.  The recomputing update (mi355cg_dist_update_reads_ghosts() != 0) evaluates A p again,
+// so its first and last owned row read the direction's ghost rows; a full update phase is then {0} or {1, 2}.
+// The flat update reads no ghost row: rows 0 and 1 run it over the whole slab, rows 2 is a no-op.
+int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, int estride, int rows, void* stream) {
     if (!c || !c->dist_active || !gathered_A) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
     const IterCfg cfg = dist_cfg(c);
     const PartSrc pa{gathered_A, nranks, 1, estride};
-    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, pick_stream(c, stream), pa);
+    hipStream_t st = pick_stream(c, stream);
+    if (!cfg.recomp) {
+        if (rows != 2) launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, st, pa);
+    } else {
+        StencilWhere w{st, &c->wl, c->grid_stencil, 0};
+        if (rows == 1) w = StencilWhere{st, &c->wl_int, c->grid_int, 0};
+        else if (rows == 2) w = StencilWhere{st, &c->wl_edge, c->grid_edge, c->grid_int};
+        c->nB_own = rows == 0 ? c->grid_stencil : c->grid_int + c->grid_edge;
+        if (!(rows == 1 && c->wl_int.nitems == 0))
+            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, st, pa, -1.0, &w);
+    }
     HIPCK(hipGetLastError());
     return MI355CG_OK;
+}
+int mi355cg_dist_update_reads_ghosts(mi355cg_handle c) {
+    if (!c || !c->dist_active) return 0;
+    return dist_cfg(c).recomp ? 1 : 0;
 }
 // Asynchronous: after the stream reaches this point the summary is in pinned host memory.
 int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, int estride, void* stream) {

@@ -129,9 +129,14 @@ class SlabEngine:
     def flip(self):
         _capi.check(self._lib.mi355cg_dist_flip(self._h))
 
-    def update(self, gathered_a: torch.Tensor, estride: int):
+    def update(self, gathered_a: torch.Tensor, estride: int, rows: int = 0):
         _capi.check(self._lib.mi355cg_dist_update(self._h, gathered_a.data_ptr(), gathered_a.numel() // estride,
-                                                  estride, self._stream()))
+                                                  estride, rows, self._stream()))
+
+    @property
+    def update_reads_ghosts(self) -> bool:
+        """True when the update phase recomputes A p (8-word iteration): its edge rows read the direction's ghost rows."""
+        return bool(self._lib.mi355cg_dist_update_reads_ghosts(self._h))
 
     def check(self, gathered_b: torch.Tensor, estride: int):
         _capi.check(self._lib.mi355cg_dist_check(self._h, gathered_b.data_ptr(), gathered_b.numel() // estride,
@@ -298,6 +303,7 @@ class DistributedCG:
         sync_every = min(sync_every, 512)
         every = params.callback_every
         it_done = 0
+        reads_ghosts = eng.update_reads_ghosts              # fixed by begin(): rule + library configuration
         while not done:
             m = min(sync_every, max(1, params.max_iterations - it_done))
             if msg and every > 0:
@@ -314,7 +320,15 @@ class DistributedCG:
                 self._gather(0)
                 if p2p:
                     tok_p = comm.halo_start(eng.halo(1))    # new direction's boundary rows (overlaps the update)
-                eng.update(self.gA, W)
+                if not reads_ghosts:
+                    eng.update(self.gA, W)                  # flat update: streams the stored A p, no ghost row read
+                elif self.overlap and comm.world > 1:
+                    eng.update(self.gA, W, rows=1)          # interior rows recompute A p without a ghost row
+                    comm.halo_wait(tok_p); tok_p = None
+                    eng.update(self.gA, W, rows=2)
+                else:
+                    comm.halo_wait(tok_p); tok_p = None
+                    eng.update(self.gA, W, rows=0)
                 self._gather(1)
                 if p2p:
                     tok_r = comm.halo_start(eng.halo(0))    # r's boundary rows (overlaps the next interior stencil)

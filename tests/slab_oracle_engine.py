@@ -29,7 +29,10 @@ class _Res:
 
 
 class OracleSlabEngine:
-    def __init__(self, n: int, y_lo: int, y_hi: int):
+    def __init__(self, n: int, y_lo: int, y_hi: int, recompute: bool = True):
+        # recompute: the update phase rebuilds A p from the stored direction INCLUDING its ghost rows (k_update_st),
+        # so it only gives the right answer if the driver has moved the direction's boundary rows before it runs
+        self.update_reads_ghosts = recompute
         self.n, self.half, self.y_lo, self.y_hi = n, n // 2, y_lo, y_hi
         self.og = OracleGrid(n, n, 1.0, 2.0, 1.0, 2.0)
         self.U = self.og.size
@@ -65,12 +68,24 @@ class OracleSlabEngine:
         self.hist = {}
         self._update_partials(self.x[self.own], self.x[self.own])
 
-    def _update_partials(self, xn, x0):
-        r = self.r[self.own]
+    def _partials_of(self, sl, xn, x0):
+        r = self.r[sl]
         d = xn - x0
-        e = xn - self.u[self.own] if self.use_u else np.zeros(1)
-        self.partB = np.array([np.dot(r, r), np.abs(r).max(initial=0.0), np.abs(d).max(initial=0.0),
-                               np.abs(e).max(initial=0.0), np.dot(d, d), np.dot(e, e)])
+        e = xn - self.u[sl] if self.use_u else np.zeros(1)
+        return np.array([np.dot(r, r), np.abs(r).max(initial=0.0), np.abs(d).max(initial=0.0),
+                         np.abs(e).max(initial=0.0), np.dot(d, d), np.dot(e, e)])
+
+    def _update_partials(self, xn, x0):
+        self.partB = self._partials_of(self.own, xn, x0)
+
+    @staticmethod
+    def _merge_partials(a, b):
+        out = a.copy()
+        for f in (FB_RR, FB_D2, FB_E2):
+            out[f] = a[f] + b[f]
+        for f in (FB_RMAX, FB_DMAX, FB_EMAX):
+            out[f] = max(a[f], b[f])
+        return out
 
     def reduce(self, which: int, with_rows: bool = False):
         rec = self._rec[which]
@@ -166,7 +181,7 @@ class OracleSlabEngine:
     def flip(self):
         self.cur ^= 1
 
-    def update(self, gathered_a: torch.Tensor, estride: int):
+    def update(self, gathered_a: torch.Tensor, estride: int, rows: int = 0):
         s = self.state
         if s["done"]:
             return
@@ -175,12 +190,36 @@ class OracleSlabEngine:
         for k in range(g.shape[0]):
             pap += g[k, 0]; rz += g[k, 1]
         alpha = (rz / pap) if self.prm.rule == RULE_MSG else (s["rr"] / pap)
-        o = self.own
-        x0 = self.x[o].copy()
-        self.x[o] = x0 + alpha * self.p[self.cur][o]
-        self.r[o] = self.r[o] - alpha * self.ap[o]
-        self._update_partials(self.x[o], x0)
-        s.update(it=s["it"] + 1, first=0, rz=rz)
+        if not self.update_reads_ghosts:                  # flat update: streams the stored A p, whole slab at once
+            if rows == 2:
+                return
+            o = self.own
+            x0 = self.x[o].copy()
+            self.x[o] = x0 + alpha * self.p[self.cur][o]
+            self.r[o] = self.r[o] - alpha * self.ap[o]
+            self._update_partials(self.x[o], x0)
+            s.update(it=s["it"] + 1, first=0, rz=rz)
+            return
+        # recomputing update: A p from the direction's owned + ghost rows, as they are in memory right now
+        halo = self.rows(max(self.y_lo - 1, 1), min(self.y_hi + 1, self.n - 1))
+        pv = np.zeros(self.U)
+        pv[halo] = self.p[self.cur][halo]
+        apn = self.og.apply(pv)
+        if rows == 0:
+            sel = [self.rows(self.y_lo, self.y_hi)]
+        elif rows == 1:
+            sel = [self.rows(self.y_lo + 1, self.y_hi - 1)] if self.y_hi - self.y_lo >= 2 else []
+        else:
+            sel = [self.rows(self.y_lo, self.y_lo)] + ([self.rows(self.y_hi, self.y_hi)] if self.y_hi > self.y_lo else [])
+        acc = np.zeros(FB_COUNT) if rows != 2 else self.partB
+        for sl in sel:
+            x0 = self.x[sl].copy()
+            self.x[sl] = x0 + alpha * self.p[self.cur][sl]
+            self.r[sl] = self.r[sl] - alpha * apn[sl]
+            acc = self._merge_partials(acc, self._partials_of(sl, self.x[sl], x0))
+        self.partB = acc
+        if rows in (0, 2):
+            s.update(it=s["it"] + 1, first=0, rz=rz)
 
     def check(self, gathered_b: torch.Tensor, estride: int):
         self._summary = dict(self.state) if self.state["done"] else self._decide(gathered_b, estride)
