@@ -163,6 +163,7 @@ def main():
                     "alg_bytes_per_launch": alg, "alg_words_per_unknown": KERNEL_ALG_WORDS[dom],
                     # what the whole iteration really has to move in this implementation, and the rate that is
                     "words_per_unknown_per_iteration": words_iter,
+                    "alg_words": KERNEL_ALG_WORDS,
                     "moved_gbps_per_iteration": round(words_iter * wbytes * U * its / 1e9, 1),
                     "other": {name: {"avg_ms": round(t[name][0], 5),
                                      "achieved": round(KERNEL_ALG_WORDS[name] * wbytes * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}

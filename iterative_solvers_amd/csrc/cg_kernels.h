@@ -26,6 +26,23 @@ constexpr int kWaves = kBlock / kWave;
 constexpr int kHist = 512;            // per-iteration norm history ring (>= sync_every)
 constexpr int kMaxPanels = 6;
 
+// ---- per-wave timing probe (diagnostic build only: -DMI355CG_WAVE_TIMING, tools/wave_timing.py) -------------------
+// Every wave of the two iteration kernels records wall_clock64() (100 MHz) at entry, after the prologue and at exit.
+#ifdef MI355CG_WAVE_TIMING
+constexpr int kWtWaves = 16384, kWtStamps = 6;
+__device__ unsigned long long g_wave_dbg[2][kWtStamps * kWtWaves];
+#define MI355CG_WT_BEGIN unsigned long long wt_[kWtStamps]; for (int i_ = 0; i_ < kWtStamps; ++i_) wt_[i_] = 0; wt_[0] = wall_clock64();
+#define MI355CG_WT_STAMP(I) wt_[I] = wall_clock64();
+#define MI355CG_WT_MID wt_[kWtStamps - 2] = wall_clock64();
+#define MI355CG_WT_END(K) do { if ((threadIdx.x & 63) == 0) { const int w_ = blockIdx.x * 4 + threadIdx.x / 64; \
+    if (w_ < kWtWaves) { wt_[kWtStamps - 1] = wall_clock64(); for (int i_ = 0; i_ < kWtStamps; ++i_) g_wave_dbg[K][kWtStamps * w_ + i_] = wt_[i_]; } } } while (0)
+#else
+#define MI355CG_WT_BEGIN
+#define MI355CG_WT_STAMP(I)
+#define MI355CG_WT_MID
+#define MI355CG_WT_END(K)
+#endif
+
 // ---- storage layout -------------------------------------------------------------------------------
 // Node (x, y) of the (N+1)x(N+1) bounding grid lives at  row_off(y) + x - base0.  Rows y <= N/2
 // (bottom-right block + its boundary row 0) only store columns [cb, cb+Pb), cb = N/2 rounded down
@@ -66,6 +83,27 @@ struct CgState {
 };
 struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2; };
 
+// What every wave needs from the state, fetched with SCALAR loads (s_load through the constant address space, one
+// request per scalar cache instead of one per wave).  Copying the whole struct made hipcc fetch half of it with
+// per-lane global loads of one address: ~4000 waves x 3 loads of the same line queued at one L2 channel and the
+// median wave waited 10-14 us of a 65 us launch for its copy of the state (tools/wave_timing.py, profiles/r01_tune_notes.md).
+// Safe because no kernel writes the state object it reads (s_in != s_out) and the scalar cache is invalidated at
+// every kernel start.
+struct StateLite { double alpha, rr, rr_prev, rz, r0norm; int it, done, first; };
+template <typename V> __device__ inline V scalar_load(const V* p) {
+    return *(const __attribute__((address_space(4))) V*)p;
+}
+// State object -> state object, by the one thread of the grid that forwards it.  Not inlined: hipcc otherwise hoists
+// the loads in front of the branch that selects that thread, and every wave of the grid fetches all 128 bytes.
+__device__ __attribute__((noinline)) void copy_state(CgState* dst, const CgState* src) { *dst = *src; }
+__device__ inline StateLite load_state_lite(const CgState* p) {
+    StateLite L;
+    L.alpha = scalar_load(&p->alpha); L.rr = scalar_load(&p->rr); L.rr_prev = scalar_load(&p->rr_prev);
+    L.rz = scalar_load(&p->rz); L.r0norm = scalar_load(&p->r0norm);
+    L.it = scalar_load(&p->it); L.done = scalar_load(&p->done); L.first = scalar_load(&p->first);
+    return L;
+}
+
 struct RuleParams {
     int rule;                 // MI355CG_RULE_*
     int max_iterations;
@@ -98,6 +136,11 @@ __device__ inline dd dd_add(dd a, dd b) {
 __device__ inline void dd_acc_prod(dd& acc, double a, double b) {          // acc += a*b, product exact
 #ifdef MI355CG_PLAIN_DOT                                                   // A/B build only: plain double accumulation
     acc.hi += a * b;
+#elif defined(MI355CG_DOT2)                                                // A/B build: Ogita-Rump-Oishi Dot2 (no renormalisation per step)
+    const double p = a * b;
+    const dd s = two_sum(acc.hi, p);
+    acc.hi = s.hi;
+    acc.lo += s.lo + fma(a, b, -p);
 #else
     const double p = a * b;
     acc = dd_add(acc, dd{p, fma(a, b, -p)});
@@ -168,7 +211,7 @@ __device__ inline dd reduce_parts_dd(const double* __restrict__ part_hi, const d
 // evaluates it from the same reduced numbers, so all blocks agree.
 struct Decision { int done, reason, converged; double beta, rr, rnorm2, r0norm, rmax, dmax, emax, d2, e2; };
 
-__device__ inline Decision decide_after_update(const CgState& s, const RuleParams& rp, double rr, double rmax,
+__device__ inline Decision decide_after_update(const StateLite& s, const RuleParams& rp, double rr, double rmax,
                                                double dmax, double emax, double d2, double e2) {
     Decision d;
     d.rr = rr; d.rnorm2 = sqrt(rr); d.rmax = rmax; d.dmax = dmax; d.emax = emax; d.d2 = d2; d.e2 = e2;
@@ -191,12 +234,13 @@ __device__ inline Decision decide_after_update(const CgState& s, const RuleParam
     return d;
 }
 
-__device__ inline void write_state_after_decision(CgState* out, HistEntry* hist, const CgState& s, const Decision& d) {
-    CgState o = s;
-    o.rr_prev = s.rr; o.rr = d.rr; o.rnorm2 = d.rnorm2; o.r0norm = d.r0norm; o.beta = d.beta;
-    o.rmax = d.rmax; o.dmax = d.dmax; o.emax = d.emax; o.d2 = d.d2; o.e2 = d.e2;
-    o.done = d.done; o.reason = d.reason; o.converged = d.converged;
-    *out = o;
+// One thread of the grid: the full state object travels through this thread only.
+__device__ inline void write_state_after_decision(CgState* out, HistEntry* hist, const CgState* in, const StateLite& s, const Decision& d) {
+    copy_state(out, in);
+    CgState* o = out;
+    o->rr_prev = s.rr; o->rr = d.rr; o->rnorm2 = d.rnorm2; o->r0norm = d.r0norm; o->beta = d.beta;
+    o->rmax = d.rmax; o->dmax = d.dmax; o->emax = d.emax; o->d2 = d.d2; o->e2 = d.e2;
+    o->done = d.done; o->reason = d.reason; o->converged = d.converged;
     if (hist) {
         HistEntry h; h.dmax = d.dmax; h.rmax = d.rmax; h.emax = d.emax; h.rnorm2 = d.rnorm2; h.d2 = d.d2; h.e2 = d.e2;
         hist[s.it % kHist] = h;
@@ -204,7 +248,7 @@ __device__ inline void write_state_after_decision(CgState* out, HistEntry* hist,
 }
 
 // Reduce the update kernel's partials (only the fields the rule needs) and decide.
-__device__ inline Decision reduce_and_decide(const CgState& s, const RuleParams& rp, const double* partB,
+__device__ inline Decision reduce_and_decide(const StateLite& s, const RuleParams& rp, const double* partB,
                                              int nB, int strideB, int esB, int want_diag, double* lds) {
     const double rr = dd_value(reduce_parts_dd(partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, esB, lds));
     double rmax = 0, dmax = 0, emax = 0, d2 = 0, e2 = 0;
@@ -252,10 +296,11 @@ template <typename V> __device__ inline void st_pol(V* p, V v, bool nt) { if (nt
 // Work-item decode shared by the stencil and the 2-D update kernel.
 struct Item { int strip, ya, yb; };
 __device__ inline Item decode_item(const WorkList& wl, int item) {
-    int pi = 0;
+    // constant indices only: a run-time index into the by-value argument struct makes hipcc spill the whole work
+    // list into per-thread LDS (14 KB per block)
+    Panel P = wl.p[0];
 #pragma unroll
-    for (int k = 1; k < kMaxPanels; ++k) if (k < wl.np && item >= wl.p[k].item0) pi = k;
-    const Panel P = wl.p[pi];
+    for (int k = 1; k < kMaxPanels; ++k) if (k < wl.np && item >= wl.p[k].item0) P = wl.p[k];
     const int local = item - P.item0;
     const int chunk = local / P.ns;
     Item it;
@@ -284,18 +329,22 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     const Geom& g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR item decode
+    MI355CG_WT_BEGIN
 
     T beta = (T)0, alpha_prev = (T)0;
     if (FUSED) {
-        const CgState s = *a.s_in;
-        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+        const StateLite s = load_state_lite(a.s_in);
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
+        MI355CG_WT_STAMP(1)
         const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, a.want_diag, lds);
-        if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, s, d);
+        MI355CG_WT_STAMP(2)
+        if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, a.s_in, s, d);
         if (d.done) return;
         beta = (T)d.beta;
         alpha_prev = (T)s.alpha;          // step length of the iteration whose x update is still pending (0 at the start)
     }
 
+    MI355CG_WT_MID
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd acc_pap = dd_zero(), acc_rz = dd_zero();
     constexpr int DIR = DESC ? -1 : 1;
@@ -407,6 +456,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         }
     }
 
+    MI355CG_WT_END(0);
     const dd tp = block_reduce_dd(acc_pap, lds);
     dd tz = dd_zero();
     if (MSG) tz = block_reduce_dd(acc_rz, lds);
@@ -437,21 +487,19 @@ template <typename T, int VEC, bool HAS_U>
 __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     typedef typename VecOf<T, VEC>::type vec_t;
     __shared__ double lds[2 * kWaves];
-    CgState s;
+    StateLite s{};
     double alpha_d = 0.0, rz = 0.0;
     if (a.init == 1) {
-        s = CgState{}; s.first = 1; s.it = 0;
+        s.first = 1; s.it = 0;
     } else if (a.init == 2) {
         // Resume after a residual replacement (mixed precision): r was overwritten with the freshly computed true
         // residual.  Measure it (alpha = 0 leaves x and r untouched) and re-arm the state WITHOUT restarting CG: the
         // direction is kept, the iteration count continues, the pending x update is gone (flushed by the host), and
-        // the beta of the next step divides by the (r, r) the interrupted step would have used.
-        s = *a.s_in;
-        if (s.done) s.rr = s.rr_prev;
-        s.done = 0; s.reason = 0; s.converged = 0; s.alpha = 0.0; s.r0norm = a.r0norm_resume;
+        // the beta of the next step divides by the (r, r) the interrupted step would have used (see the state write below).
+        s = load_state_lite(a.s_in);
     } else {
-        s = *a.s_in;
-        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+        s = load_state_lite(a.s_in);
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
         const double pap = dd_value(reduce_parts_dd(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
         if (a.rule == 0) {
             rz = dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
@@ -563,9 +611,17 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
         a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
         a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
         if (blockIdx.x == 0) {
-            CgState o = s;
-            if (!a.init) { o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz; }
-            *a.s_out = o;
+            CgState* o = a.s_out;
+            if (a.init == 1) {
+                *o = CgState{};
+                o->first = 1;
+            } else {
+                copy_state(a.s_out, a.s_in);
+                if (a.init == 2) {
+                    if (s.done) o->rr = s.rr_prev;
+                    o->done = 0; o->reason = 0; o->converged = 0; o->alpha = 0.0; o->r0norm = a.r0norm_resume;
+                } else { o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; }
+            }
         }
     }
 }
@@ -576,12 +632,19 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
 // evaluates the 5-point formula again -- same operands, same operation order, hence the same bits as the values
 // the stencil launch reduced into (Ap, p) -- so A p never touches HBM.  An iteration moves 8 words per unknown
 // (stencil launch: r, p_old, x in; p, x out; this launch: p, r in; r out) instead of 9 (REL_2NORM) or 10 (MSG).
-// FULL adds the x update and the MSG norms (|dx|, |x - u|), element-wise identical to k_update.
+// XM selects what happens to x in this launch:
+//   0  nothing (odd iterations of the two-step scheme below);
+//   1  x += alpha p plus the MSG norms (|dx|, |x - u|), element-wise identical to k_update;
+//   2  two-step update on even iterations k: x = (x + alpha_{k-1} p_{k-1}) + alpha_k p_k.  p_{k-1} is still intact in the
+//      other direction buffer, alpha_{k-1} is in the state.  Same operations in the same order as two single updates,
+//      but x is read and written once per two iterations: 7.5 words per unknown and iteration on average
+//      (stencil launch 3: r, p in, p out; this launch 3 on odd iterations, 6 on even ones).
 template <typename T>
 struct UpdateStArgs {
     Geom g;
     WorkList wl;
     const T* p;          // current direction, ghost rows valid
+    const T* pprev;      // XM == 2: the previous direction (the other ping-pong buffer)
     T* r; T* x; const T* u;
     const T* zero; T* trash;
     const double* partA; int nA, strideA, esA;
@@ -591,16 +654,17 @@ struct UpdateStArgs {
     int reverse;         // take the items from the last to the first (start where the stencil launch ended)
 };
 
-template <typename T, int VEC, bool FULL, bool HAS_U, int DEPTH, bool DESC>
+template <typename T, int VEC, int XM, bool HAS_U, int DEPTH, bool DESC>
 __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     typedef typename VecOf<T, VEC>::type vec_t;
     __shared__ double lds[2 * kWaves];
     const Geom& g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    MI355CG_WT_BEGIN
 
-    const CgState s = *a.s_in;
-    if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+    const StateLite s = load_state_lite(a.s_in);
+    if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
     double alpha_d, rz = 0.0;
     {
         const double pap = dd_value(reduce_parts_dd(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
@@ -612,12 +676,15 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
         }
     }
     const T alpha = (T)alpha_d;
+    MI355CG_WT_MID
+    const T alpha_prev = (T)s.alpha;       // XM == 2: step length of the previous iteration (0 after init / resume)
+    constexpr bool FULL = XM == 1;
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
     double s_rmax = 0, s_dmax = 0, s_emax = 0;
     constexpr int DIR = DESC ? -1 : 1;
 
-    struct Raw { vec_t p, r, x, u; T pe; };
+    struct Raw { vec_t p, r, x, u, pp; T pe; };
 
     for (int idx = blockIdx.x * kWaves + wave; idx < a.wl.nitems; idx += gridDim.x * kWaves) {
         const Item it = decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx);
@@ -637,7 +704,8 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
             w.p = *reinterpret_cast<const vec_t*>(v ? a.p + off + x : a.zero);
             const bool vo = v && own;
             w.r = *reinterpret_cast<const vec_t*>(vo ? a.r + off + x : a.zero);
-            if (FULL) w.x = *reinterpret_cast<const vec_t*>(vo ? a.x + off + x : a.zero);
+            if (XM != 0) w.x = *reinterpret_cast<const vec_t*>(vo ? a.x + off + x : a.zero);
+            if (XM == 2) w.pp = *reinterpret_cast<const vec_t*>(vo ? a.pprev + off + x : a.zero);
             if (FULL && HAS_U) w.u = *reinterpret_cast<const vec_t*>(vo ? a.u + off + x : a.zero);
             const bool ev = row_ok && own && edge && xe >= cmin && xe < g.xlim;
             w.pe = *(ev ? a.p + off + xe : a.zero);
@@ -690,6 +758,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                         const double rd = (double)rn[j];
                         dd_acc_prod(s_rr, rd, rd);
                         s_rmax = fmax(s_rmax, fabs(rd));
+                        if (XM == 2) xn[j] = (c.x[j] + alpha_prev * c.pp[j]) + alpha * cc;   // two x = x + alpha*z steps
                         if (FULL) {
                             xn[j] = c.x[j] + alpha * cc;                 // x = x + alpha*z        msg_solver.cpp:105-107
                             const double dx = (double)(xn[j] - c.x[j]);  // diff = x - x_prev      msg_solver.cpp:124-127
@@ -706,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                         const bool sv = xin && x >= cmin;
                         const long long off = row_off(g, y) - g.base0 + x;
                         *reinterpret_cast<vec_t*>(sv ? a.r + off : a.trash) = rn;
-                        if (FULL) *reinterpret_cast<vec_t*>(sv ? a.x + off : a.trash) = xn;
+                        if (XM != 0) *reinterpret_cast<vec_t*>(sv ? a.x + off : a.trash) = xn;
                     }
                     p_b = c.p; c = w;
                 }
@@ -714,6 +783,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
         }
     }
 
+    MI355CG_WT_END(1);
     const dd t_rr = block_reduce_dd(s_rr, lds);
     const double t_rmax = block_reduce<true>(s_rmax, lds);
     double t_dmax = 0, t_emax = 0; dd t_d2 = dd_zero(), t_e2 = dd_zero();
@@ -726,9 +796,9 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
         a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
         a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
         if (blockIdx.x == 0) {
-            CgState o = s;
-            o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz;
-            *a.s_out = o;
+            copy_state(a.s_out, a.s_in);
+            CgState* o = a.s_out;
+            o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz;
         }
     }
 }
@@ -851,10 +921,10 @@ struct CheckArgs {
 };
 __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
     __shared__ double lds[2 * kWaves];
-    const CgState s = *a.s_in;
-    if (s.done) { if (threadIdx.x == 0) *a.summary = s; return; }
+    const StateLite s = load_state_lite(a.s_in);
+    if (s.done) { if (threadIdx.x == 0) copy_state(a.summary, a.s_in); return; }
     const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, 1, lds);
-    if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, s, d);
+    if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, a.s_in, s, d);
 }
 
 // x += alpha * p over the owned range: the x update still pending when an XUPD loop ends.

@@ -20,10 +20,10 @@ struct XpayArgs {
 };
 __global__ __launch_bounds__(kBlock) void k_csr_xpay(const XpayArgs a) {
     __shared__ double lds[2 * kWaves];
-    const CgState s = *a.s_in;
-    if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
+    const StateLite s = load_state_lite(a.s_in);
+    if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
     const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, a.want_diag, lds);
-    if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, s, d);
+    if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, a.s_in, s, d);
     if (d.done) return;
     const double beta = d.beta;
     const long long stride = (long long)gridDim.x * kBlock;
@@ -43,7 +43,7 @@ constexpr int kCsrChunk = 2048;
 __global__ __launch_bounds__(kBlock) void k_csr_spmv(const SpmvArgs a) {
     __shared__ double prod[kCsrChunk];
     __shared__ double lds[2 * kWaves];
-    if (a.s_in && a.s_in->done) return;
+    if (a.s_in && scalar_load(&a.s_in->done)) return;
     dd acc_xy = dd_zero(), acc_rx = dd_zero();
     const long long nblk = (a.A.n + kBlock - 1) / kBlock;
     for (long long rb = blockIdx.x; rb < nblk; rb += gridDim.x) {

@@ -71,7 +71,7 @@ struct mi355cg_ctx {
     int update_mode = 1, stencil_desc = 1, update_desc = 0, update_unroll = 4;   // launch-shape knobs (env)
     int nt_mask = 0;                    // cache-policy bits (NT_*), env MI355CG_NT
     int xfuse = 1, xdepth = 2;          // REL_2NORM: fold the x update into the next stencil launch (env MI355CG_XFUSE, MI355CG_XDEPTH)
-    int recompute = 1, udepth = 4, udepth_full = 2;      // update phase rebuilds A p from the stored direction instead of streaming it (env MI355CG_RECOMPUTE, MI355CG_UDEPTH)
+    int recompute = 1, udepth = 2, udepth_full = 2, msg_depth = 2, x2step = 1, sdepth = 2;      // update phase rebuilds A p from the stored direction instead of streaming it (env MI355CG_RECOMPUTE, MI355CG_UDEPTH)
     int nB_own = 0;                     // partB slots written by the last update-phase launch(es) of this context
     int strideA = 0, strideB = 0;
     struct Plan { WorkList wl; int grid_stencil = 0, grid_update = 0, rows_per_item = 0; } plan32;   // fp32 kernels (VEC = 4)
@@ -174,14 +174,23 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     WorkList dry{}; 
     const long long strip_rows = add_panels(g, vec, g.y_lo, g.y_hi, 0, dry);
     const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 4096));
-    int ty = (int)((strip_rows + target_waves - 1) / target_waves);
-    // enough items to fill the chip, but never taller than MAX_ROWS: beyond N = 4096 several rounds of 24-row items beat
-    // one round of taller ones (+5 % at N = 8192, profiles/r01_tune_notes.md)
-    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), std::min(ty, env_int("MI355CG_MAX_ROWS", 24)));
+    // Items are dealt to the resident waves round-robin, so the launch takes `rounds` full items per wave -- and one more
+    // if the item count spills over rounds * waves by even a single item (N = 4096 with 24-row items: 4128 items for
+    // 4096 waves, i.e. 32 waves ran twice as long as the rest and the launch waited for them).  Pick the number of
+    // rounds from MAX_ROWS (beyond N = 4096 several rounds of ~24-row items beat one round of taller ones, +5 % at
+    // N = 8192, profiles/r01_tune_notes.md), then the smallest item height whose item count fits into those rounds.
+    const int max_rows = std::max(1, env_int("MI355CG_MAX_ROWS", 24));
+    const long long rounds = std::max<long long>(1, (strip_rows + (long long)target_waves * max_rows - 1) / ((long long)target_waves * max_rows));
+    int ty = (int)((strip_rows + rounds * target_waves - 1) / (rounds * target_waves));
+    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), ty);
     if (env_int("MI355CG_ROWS", 0) > 0) ty = env_int("MI355CG_ROWS", 0);
+    for (int tries = 0; tries < 64; ++tries) {
+        c->wl = WorkList{};
+        add_panels(g, vec, g.y_lo, g.y_hi, ty, c->wl);
+        if (env_int("MI355CG_ROWS", 0) > 0 || c->wl.nitems <= rounds * target_waves || env_int("MI355CG_FIT_ROUNDS", 1) == 0) break;
+        ++ty;
+    }
     c->rows_per_item = ty;
-    c->wl = WorkList{};
-    add_panels(g, vec, g.y_lo, g.y_hi, ty, c->wl);
     const int max_blocks = std::max(1, env_int("MI355CG_STENCIL_BLOCKS", 1024));
     c->grid_stencil = std::max(1, std::min(max_blocks, (c->wl.nitems + kWaves - 1) / kWaves));
     // slab split for halo/compute overlap: edge rows (need the neighbours' ghost rows) and interior rows
@@ -205,8 +214,11 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     c->xdepth = env_int("MI355CG_XDEPTH", 2);
     c->use_graph = env_int("MI355CG_GRAPH", -1);
     c->recompute = env_int("MI355CG_RECOMPUTE", 1);
-    c->udepth = env_int("MI355CG_UDEPTH", 4);
+    c->udepth = env_int("MI355CG_UDEPTH", 2);
     c->udepth_full = env_int("MI355CG_UDEPTH_FULL", 2);
+    c->msg_depth = env_int("MI355CG_MSG_DEPTH", 2);
+    c->x2step = env_int("MI355CG_X2STEP", 1);        // REL_2NORM: x is updated every second iteration, two steps at once (7.5 words)
+    c->sdepth = env_int("MI355CG_SDEPTH", 2);
     c->nB_own = c->grid_update;
 }
 
@@ -266,7 +278,7 @@ void launch_apply(const mi355cg_ctx* c, const T* v, T* out) {
     launch_stencil_depth<T, VEC, false, false>(c, a, w);
 }
 
-struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool xfuse = false; bool recomp = false; };
+struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool xfuse = false; bool recomp = false; bool x2 = false; };
 
 // Phase A'.  Does NOT flip c->cur (a slab's interior and edge launches share one direction pair).
 template <typename T, int VEC>
@@ -279,40 +291,56 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     if (cfg.recomp && cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) {        // A p is not stored: the update launch recomputes it
         dim3 grid(w.grid), block(kBlock);
-        if (c->depth == 2) hipLaunchKernelGGL((k_stencil<T, VEC, true, true, 2, false, false, true>), grid, block, 0, w.stream, a);
+        // 2 rows in flight: 4 rows cost a fourth wave per SIMD and measured 9 % slower (profiles/r01_tune_notes.md)
+        if (c->msg_depth == 2) hipLaunchKernelGGL((k_stencil<T, VEC, true, true, 2, false, false, true>), grid, block, 0, w.stream, a);
         else hipLaunchKernelGGL((k_stencil<T, VEC, true, true, 4, false, false, true>), grid, block, 0, w.stream, a);
     }
     else if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a, w);
+    else if (cfg.x2) {          // x is handled by the update launch (every second iteration): r, p in, p out
+        dim3 grid(w.grid), block(kBlock);
+        if (c->sdepth == 2) hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 2, false, false, true>), grid, block, 0, w.stream, a);
+        else hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 4, false, false, true>), grid, block, 0, w.stream, a);
+    }
     else if (cfg.xfuse && cfg.recomp) { a.x = x; launch_stencil_xupd<T, VEC, true>(c, a, w); }
     else if (cfg.xfuse) { a.x = x; launch_stencil_xupd<T, VEC, false>(c, a, w); }
     else launch_stencil_depth<T, VEC, true, false>(c, a, w);
 }
+#ifdef MI355CG_WAVE_TIMING     // diagnostic build: MI355CG_FAKE_NB=1 makes the prologues reduce ONE partial (wrong numbers, right timing of everything else)
+static int fake_nb() { static int v = env_int("MI355CG_FAKE_NB", 0); return v; }
+PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, fake_nb() ? 1 : c->nB_own, c->strideB, 1}; }
+PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, fake_nb() ? 1 : c->grid_stencil, c->strideA, 1}; }
+#else
 PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, c->nB_own, c->strideB, 1}; }
 PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, c->grid_stencil, c->strideA, 1}; }
+#endif
 
 template <typename T, int VEC>
 void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, bool init,
-                   hipStream_t stream, const PartSrc& pa, double resume_r0norm = -1.0, const StencilWhere* where = nullptr) {
+                   hipStream_t stream, const PartSrc& pa, double resume_r0norm = -1.0, const StencilWhere* where = nullptr,
+                   const T* pprev = nullptr) {
     if (cfg.recomp && !init && resume_r0norm < 0.0) {
         // recomputing update on the stencil's work items, marched the other way (it starts on what the stencil touched last)
         const StencilWhere w = where ? *where : StencilWhere{stream, &c->wl, c->grid_stencil, 0};
         UpdateStArgs<T> a{};
         a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC); a.wl = *w.wl;
-        a.p = p; a.r = r; a.x = x; a.u = u;
+        a.p = p; a.r = r; a.x = x; a.u = u; a.pprev = pprev;
         a.zero = reinterpret_cast<const T*>(c->zero_blk); a.trash = reinterpret_cast<T*>(c->trash_blk);
         a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
         a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slotA;
         a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = c->update_desc;
         dim3 grid(w.grid), block(kBlock);
-        const int ud = cfg.xfuse ? c->udepth : c->udepth_full;     // rows in flight: the FULL variants carry x (and u) too
-#define MI355CG_UST(FULL, HASU) do { \
-        if (c->update_desc) { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 2, true>), grid, block, 0, w.stream, a); \
-                              else hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 4, true>), grid, block, 0, w.stream, a); } \
-        else                { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 2, false>), grid, block, 0, w.stream, a); \
-                              else hipLaunchKernelGGL((k_update_st<T, VEC, FULL, HASU, 4, false>), grid, block, 0, w.stream, a); } } while (0)
-        if (cfg.xfuse) MI355CG_UST(false, false);
-        else if (cfg.has_u) MI355CG_UST(true, true);
-        else MI355CG_UST(true, false);
+        const bool heavy = cfg.x2 ? (c->cur == 0 && pprev) : !cfg.xfuse;     // this launch also streams x (and p_prev or u)
+        const int ud = heavy ? c->udepth_full : c->udepth;                    // rows in flight
+#define MI355CG_UST(XM, HASU) do { \
+        if (c->update_desc) { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, true>), grid, block, 0, w.stream, a); \
+                              else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 4, true>), grid, block, 0, w.stream, a); } \
+        else                { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, false>), grid, block, 0, w.stream, a); \
+                              else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 4, false>), grid, block, 0, w.stream, a); } } while (0)
+        // c->cur was flipped after this iteration's stencil launch: it is the iteration number's parity
+        if (cfg.x2) { if (c->cur == 0 && pprev) MI355CG_UST(2, false); else MI355CG_UST(0, false); }
+        else if (cfg.xfuse) MI355CG_UST(0, false);
+        else if (cfg.has_u) MI355CG_UST(1, true);
+        else MI355CG_UST(1, false);
 #undef MI355CG_UST
         return;
     }
@@ -592,7 +620,7 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
             c->cur ^= 1;
             prof_end(c, 0, e0);
             prof_begin(c, 1, &e0);
-            launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[c->cur], c->apf, (const float*)nullptr, false, c->stream, own_partA(c));
+            launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[c->cur], c->apf, (const float*)nullptr, false, c->stream, own_partA(c), -1.0, nullptr, c->pf[c->cur ^ 1]);
             prof_end(c, 1, e0);
         }
         HIPCK(hipGetLastError());
@@ -601,7 +629,7 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
     }
     *its = c->summary_h->it;
     c->cur = *its & 1;
-    if (cfg.xfuse && *its > 0) {        // the last inner iteration's x += alpha*p is still pending
+    if (cfg.xfuse && *its > 0 && (!cfg.x2 || (*its & 1))) {        // the last inner iteration's x += alpha*p is still pending (two-step scheme: only after an odd count)
         hipLaunchKernelGGL((k_flush_x<float>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream,
                            c->g.own_begin, c->g.own_len, c->xf, c->pf[c->cur], (float)c->summary_h->alpha);
         HIPCK(hipGetLastError());
@@ -651,6 +679,7 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
         IterCfg cfg = make_cfg(&ip);
         cfg.xfuse = c->xfuse && c->update_mode == 0;
         cfg.recomp = c->recompute && cfg.xfuse;
+        cfg.x2 = cfg.recomp && c->x2step;
         int its = 0;
         const double resume = (!restart && outer > 0) ? rnorm : -1.0;
         if (int rc = inner_cg_f32(c, cfg, sync_every, stop_flag, &its, &interrupted, resume)) return rc;
@@ -935,6 +964,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     const bool diag = cfg.want_diag != 0;
     cfg.xfuse = c->xfuse && !msg && !diag && !cfg.has_u && c->update_mode == 0;     // x update rides in the stencil launch
     cfg.recomp = c->recompute && c->update_mode == 0 && (cfg.xfuse || msg);        // 8-word iteration: A p is never stored
+    cfg.x2 = cfg.recomp && cfg.xfuse && c->x2step;                                 // 7.5 words: x every second iteration, two steps at once
     c->nB_own = cfg.recomp ? c->grid_stencil : c->grid_update;
     if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
 
@@ -991,7 +1021,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
                 prof_begin(c, 1, &e0);
                 IterCfg ucfg = cfg;
                 ucfg.has_u = cfg.has_u && need_u(it_done + k + 1);      // skip the u stream when nothing reads the error norm
-                launch_update<double, 2>(c, ucfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c));
+                launch_update<double, 2>(c, ucfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c), -1.0, nullptr, c->p[c->cur ^ 1]);
                 prof_end(c, 1, e0);
                 if (diag) {
                     // MatrixFreeSolver's per-iteration report: second apply for the TRUE residual
@@ -1056,7 +1086,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     // Launches enqueued after the stop decision return in their prologue but still flipped c->cur on the
     // host: the direction of the last REAL iteration is p[it % 2] (the solve starts with cur = 0).
     c->cur = fin.it & 1;
-    if (cfg.xfuse && fin.it > 0) {      // the last iteration's x += alpha*p has not been applied yet
+    if (cfg.xfuse && fin.it > 0 && (!cfg.x2 || (fin.it & 1))) {      // the last iteration's x += alpha*p has not been applied yet (two-step scheme: only after an odd count)
         hipLaunchKernelGGL((k_flush_x<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream,
                            c->g.own_begin, c->g.own_len, c->x, c->p[c->cur], fin.alpha);
         HIPCK(hipGetLastError());
@@ -1072,6 +1102,13 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     }
     c->solved = true;
     prof_collect(c);
+#ifdef MI355CG_WAVE_TIMING
+    if (const char* path = getenv("MI355CG_WAVE_TIMING_OUT")) {     // diagnostic build: per-wave timestamps of the last launch of each kernel
+        std::vector<unsigned long long> buf(2 * kWtStamps * kWtWaves);
+        HIPCK(hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_wave_dbg), buf.size() * sizeof(unsigned long long)));
+        if (FILE* f = fopen(path, "wb")) { fwrite(buf.data(), sizeof(unsigned long long), buf.size(), f); fclose(f); }
+    }
+#endif
     mi355cg_results res{};
     res.iterations = fin.it;
     res.converged = interrupted ? 0 : fin.converged;
@@ -1176,6 +1213,7 @@ static IterCfg dist_cfg(const mi355cg_ctx* c) {
     IterCfg cfg = make_cfg(&c->dist_prm);
     cfg.xfuse = c->xfuse && c->update_mode == 0 && c->dist_prm.rule == MI355CG_RULE_REL_2NORM && !cfg.has_u;
     cfg.recomp = c->recompute && c->update_mode == 0 && (cfg.xfuse || c->dist_prm.rule == MI355CG_RULE_MSG_MAXNORM);
+    cfg.x2 = cfg.recomp && cfg.xfuse && c->x2step;
     return cfg;
 }
 
@@ -1299,7 +1337,7 @@ int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, 
         else if (rows == 2) w = StencilWhere{st, &c->wl_edge, c->grid_edge, c->grid_int};
         c->nB_own = rows == 0 ? c->grid_stencil : c->grid_int + c->grid_edge;
         if (!(rows == 1 && c->wl_int.nitems == 0))
-            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, st, pa, -1.0, &w);
+            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, st, pa, -1.0, &w, c->p[c->cur ^ 1]);
     }
     HIPCK(hipGetLastError());
     return MI355CG_OK;
@@ -1325,7 +1363,7 @@ int mi355cg_dist_finish(mi355cg_handle c, void* stream) {
     const IterCfg cfg = dist_cfg(c);
     const CgState fin = *c->summary_h;
     c->cur = fin.it & 1;                 // launches after the stop decision were no-ops but flipped the host-side index
-    if (cfg.xfuse && fin.it > 0) {
+    if (cfg.xfuse && fin.it > 0 && (!cfg.x2 || (fin.it & 1))) {
         hipLaunchKernelGGL((k_flush_x<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, pick_stream(c, stream),
                            c->g.own_begin, c->g.own_len, c->x, c->p[c->cur], fin.alpha);
         HIPCK(hipGetLastError());

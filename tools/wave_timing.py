@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of the last stencil / update launch (diagnostic build, -DMI355CG_WAVE_TIMING).
+Usage (GPU box): MI355CG_LIB=iterative_solvers_amd/libmi355cg_wt.so python tools/wave_timing.py [N] [iters]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 51
+OUT = "/tmp/wave_timing.bin"
+os.environ["MI355CG_WAVE_TIMING_OUT"] = OUT
+import iterative_solvers_amd as isa
+from iterative_solvers_amd import _capi
+
+s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+p = isa.default_params(_capi.RULE_REL_2NORM)
+p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = ITERS, 1, 0, 0, 500
+s._handle.solve(p)
+s._handle.solve(p)
+d = np.fromfile(OUT, dtype=np.uint64).reshape(2, -1, 6).astype(np.int64)
+for k, name in enumerate(("stencil", "update")):
+    w = d[k]
+    w = w[w[:, 5] > 0]
+    t0 = w[:, 0].min()
+    start, mid, end = (w[:, 0] - t0) / 100.0, (w[:, 4] - t0) / 100.0, (w[:, 5] - t0) / 100.0     # microseconds
+    q = lambda v: " ".join(f"{np.percentile(v, x):7.1f}" for x in (0, 5, 25, 50, 75, 95, 100))
+    print(f"{name}: {len(w)} waves, launch span {end.max():.1f} us")
+    print(f"   percentiles          min      5     25     50     75     95    max")
+    print(f"   wave start      {q(start)}")
+    print(f"   prologue length {q(mid - start)}")
+    if w[:, 1].max() > 0:
+        print(f"     state loaded  {q((w[:, 1] - w[:, 0]) / 100.0)}")
+        print(f"     reduce+decide {q((w[:, 2] - w[:, 1]) / 100.0)}")
+        print(f"     rest          {q((w[:, 4] - w[:, 2]) / 100.0)}")
+    print(f"   main loop length{q(end - mid)}")
+    print(f"   wave end        {q(end)}")
+    hist, edges = np.histogram(end, bins=12)
+    print("   end-time histogram:", " ".join(f"{e:.0f}:{h}" for h, e in zip(hist, edges[:-1])))
+    # where are the slow waves?  one item per wave at N = 4096: wave index = item index
+    idx = np.nonzero(d[k][:, 5] > 0)[0]
+    dur = end - mid
+    nb = 16
+    edges = np.linspace(0, idx.max() + 1, nb + 1)
+    print("   main loop (us) by item-index bin :", " ".join(f"{dur[(idx >= edges[i]) & (idx < edges[i + 1])].mean():5.1f}" for i in range(nb)))
+    print("   main loop (us) by XCD (block % 8):", " ".join(f"{dur[(idx // 4) % 8 == x].mean():5.1f}" for x in range(8)))
+    print("   main loop (us) by wave in block  :", " ".join(f"{dur[idx % 4 == x].mean():5.1f}" for x in range(4)))
+    print("   main loop (us) by item % 32      :", " ".join(f"{dur[idx % 32 == x].mean():5.1f}" for x in range(32)))
