@@ -28,9 +28,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured-achievable
 ALG_BYTES_PER_UNKNOWN = 88.0    # 11 words fp64 per unknown per iteration
 # Compulsory words per unknown and launch of THIS implementation -- what roofline.achieved counts.
-# Default (A p recomputed in the update launch, never stored): REL_2NORM stencil launch = read r,p,x / write p,x = 5,
-# update launch = read p,r / write r = 3 (8 per iteration); MSG: stencil read r,p / write p = 3, update read p,r,x / write r,x = 5.
-# MI355CG_RECOMPUTE=0: REL_2NORM 6 + 3 (A p stored and streamed back), MSG or MI355CG_XFUSE=0: 4 + 6.
+# Default REL_2NORM (A p recomputed in the update launch, never stored; x updated every second iteration, two steps at
+# once): stencil launch = read r,p / write p = 3; update launch = read p,r / write r = 3 on odd iterations and
+# read p,p_prev,r,x / write r,x = 6 on even ones, 4.5 on average (7.5 per iteration).
+# MSG: stencil read r,p / write p = 3, update read p,r,x / write r,x = 5.
+# MI355CG_X2STEP=0: REL_2NORM 5 + 3.  MI355CG_RECOMPUTE=0: REL_2NORM 6 + 3 (A p stored and streamed back), MSG or MI355CG_XFUSE=0: 4 + 6.
+KERNEL_ALG_WORDS_X2 = {"stencil": 3, "update": 4.5}
 KERNEL_ALG_WORDS_RECOMP = {"stencil": 5, "update": 3}
 KERNEL_ALG_WORDS_RECOMP_MSG = {"stencil": 3, "update": 5}
 KERNEL_ALG_WORDS_XFUSE = {"stencil": 6, "update": 3}
@@ -146,7 +149,10 @@ def main():
         run(k, True)
         xfuse = args.rule == "rel2" and os.environ.get("MI355CG_XFUSE", "1") != "0"
         recomp = os.environ.get("MI355CG_RECOMPUTE", "1") != "0" and (xfuse or args.rule == "msg")
-        if recomp:
+        x2 = recomp and xfuse and os.environ.get("MI355CG_X2STEP", "1") != "0"
+        if x2:
+            KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_X2
+        elif recomp:
             KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_RECOMP if xfuse else KERNEL_ALG_WORDS_RECOMP_MSG
         else:
             KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_XFUSE if xfuse else KERNEL_ALG_WORDS_PLAIN

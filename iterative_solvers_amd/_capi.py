@@ -72,6 +72,13 @@ def load():
         except Exception as e:  # pre-built .so shipped to a box without hipcc is fine
             if not os.path.exists(path):
                 raise RuntimeError(f"libmi355cg.so is missing and could not be built: {e}") from e
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If this library pulled /opt/rocm's copies
+    # into the process first, torch would come up without a GPU (torch.cuda.is_available() == False) as soon as it is
+    # imported later for device tensors or RCCL.  Importing torch first makes both sides share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     H = C.c_void_p
     L.mi355cg_create.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.POINTER(H)]

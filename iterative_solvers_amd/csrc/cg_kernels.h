@@ -274,8 +274,6 @@ struct StencilArgs {
     T* pout;             // FUSED: new direction (ping-pong partner of pin)
     T* ap;               // A_h * (new direction | input vector)
     T* x;                // XUPD: solution vector updated with the previous iteration's step
-    const T* zero;       // >= 16 bytes of zeros: what lanes / rows without data load
-    T* trash;            // >= 16 bytes nobody reads: where lanes outside the stored columns store
     const double* partB; int nB, strideB, esB;  // update-kernel partials to reduce in the prologue (count, field stride, element stride)
     double* partA; int strideA, slotA;          // this kernel's partials (field-major); first slot of this launch
     const CgState* s_in; CgState* s_out;        // state written by the update kernel / by this kernel
@@ -292,6 +290,62 @@ template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_
 enum { NT_B_X = 1, NT_B_AP = 2, NT_B_P = 16, NT_B_R = 32, NT_B_U = 256 };
 template <typename V> __device__ inline V ld_pol(const V* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 template <typename V> __device__ inline void st_pol(V* p, V v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// ---- wave-uniform addressing --------------------------------------------------------------------------------
+// The iteration kernels were instruction-issue bound, not bandwidth bound (SQ counters + tools/wave_timing.py: ~216
+// issued instructions per 128-column row, of which ~60 are the fp64 arithmetic; the SIMDs' issue slots ~100 % busy and
+// the waves dispatched last onto a CU a third slower than the first).  Most of the overhead was 64-bit per-lane address
+// arithmetic and pointer selects.  Here every stream is a buffer resource (base = first row of the item, wave-uniform,
+// in SGPRs), a row is an SGPR byte offset that advances by the row pitch, and the lane contributes ONE 32-bit byte
+// offset that never changes while the item is marched.  A lane that must not touch memory carries an offset beyond
+// num_records: the hardware range check returns 0 for its load and drops its store.  No load or store sits in an
+// exec-masked region, so hipcc waits with counted vmcnt(N) and the rows prefetched for later iterations really stay
+// in flight.  In-row neighbours come through DPP wave shifts, not LDS permutes.
+constexpr int kOob = (int)0x80000000;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ inline rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <typename V> __device__ inline V buf_load(rsrc_t r, int voff, int soff) {
+    if constexpr (sizeof(V) == 16) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    else if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    else { static_assert(sizeof(V) == 4, "buf_load: 4, 8 or 16 bytes"); return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
+}
+template <typename V> __device__ inline void buf_store(V v, rsrc_t r, int voff, int soff) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
+    else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, voff, soff, 0);
+    else { static_assert(sizeof(V) == 4, "buf_store: 4, 8 or 16 bytes"); __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0); }
+}
+// value of the lane below (lane - 1) / above (lane + 1); lane 0 / lane 63 get 0 and are overridden by the caller
+__device__ inline int dpp_from_below(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+__device__ inline int dpp_from_above(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
+__device__ inline float lane_below(float v) { return __builtin_bit_cast(float, dpp_from_below(__builtin_bit_cast(int, v))); }
+__device__ inline float lane_above(float v) { return __builtin_bit_cast(float, dpp_from_above(__builtin_bit_cast(int, v))); }
+__device__ inline double lane_below(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)dpp_from_below((int)(unsigned)u), hi = (unsigned)dpp_from_below((int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ inline double lane_above(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)dpp_from_above((int)(unsigned)u), hi = (unsigned)dpp_from_above((int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// bytes from row y to row y + 1 of the storage layout (rows <= half are Pb wide and start at column cb)
+template <typename T> __device__ inline int row_step(const Geom& g, int y) { return (y + 1 <= g.half ? g.Pb : g.Pu) * (int)sizeof(T); }
+
+// Byte offset of a lane's first column x in a row of the bottom block (columns >= cb stored) or of the upper block,
+// kOob for a lane outside the stored columns; the same for the single element beyond a wave-edge lane.
+template <typename T> __device__ inline int lane_off(const Geom& g, int x, bool bottom_row) {
+    return (x < g.xlim && x >= (bottom_row ? g.cb : 0)) ? x * (int)sizeof(T) : kOob;
+}
+template <typename T, int VEC> __device__ inline int edge_off(const Geom& g, int x, int lane, bool bottom_row) {
+    const int xe = lane == 0 ? x - 1 : x + VEC;
+    const bool edge = lane == 0 || lane == kWave - 1;
+    return (edge && xe >= (bottom_row ? g.cb : 0) && xe < g.xlim) ? xe * (int)sizeof(T) : kOob;
+}
 
 // Work-item decode shared by the stencil and the 2-D update kernel.
 struct Item { int strip, ya, yb; };
@@ -312,7 +366,7 @@ __device__ inline Item decode_item(const WorkList& wl, int item) {
 
 // One wave marches a (64*VEC)-column strip over rows ya..yb, ascending (DESC=false) or
 // descending (DESC=true), keeping three converted rows in registers and DEPTH raw rows in
-// flight.  In-row neighbours come from the adjacent lane (wave shuffle); the two wave-edge
+// flight.  In-row neighbours come from the adjacent lane (DPP wave shift); the two wave-edge
 // lanes load their outside neighbour themselves.  The update kernel marches the same chunks
 // in the opposite direction, so each kernel starts on the rows the previous one touched last
 // (they are still in the 256 MiB Infinity Cache when the vectors are ~100 MB each).
@@ -354,27 +408,42 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     for (int item = blockIdx.x * kWaves + wave; item < a.wl.nitems; item += gridDim.x * kWaves) {
         const Item it = decode_item(a.wl, item);
         const int x = it.strip * (kWave * VEC) + lane * VEC;
-        const bool xin = x < g.xlim;
-        const bool edge = (lane == 0) || (lane == kWave - 1);
-        const int xe = lane == 0 ? x - 1 : x + VEC;
         const int nrows = it.yb - it.ya + 1;
         const int ystart = DESC ? it.yb : it.ya;
+        const int y0 = it.ya - 1;                                   // lowest row the item touches (halo)
+        const long long base_el = row_off(g, y0) - g.base0;
+        const rsrc_t rs_p = make_rsrc(a.pin + base_el);
+        const rsrc_t rs_r = make_rsrc(FUSED ? a.r + base_el : a.pin + base_el);
+        const rsrc_t rs_x = make_rsrc(XUPD ? a.x + base_el : a.pin + base_el);
+        const rsrc_t rs_po = make_rsrc(FUSED ? a.pout + base_el : a.pin + base_el);
+        const rsrc_t rs_ap = make_rsrc(NOAP ? a.pin + base_el : a.ap + base_el);
+        const bool bot_item = it.ya <= g.half;                      // all own rows lie in one block of the L
+        const int vo_own = lane_off<T>(g, x, bot_item);             // lane offset of the item's own rows (loads and stores)
+        const int ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
+        const int vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);            // the halo row behind the first own row
+        const int vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);     // the halo row ahead of the last one
+        const int xint0 = bot_item ? g.half + 1 : 1;                // first interior column of the own rows
+        bool in_j[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
 
-        // Branch-free loads: a lane (or a whole row) that has nothing to load reads the 16-byte zero
-        // block instead, so there is no exec-masked region around any load and hipcc can wait with
-        // counted vmcnt(N) -- the rows prefetched for later iterations really stay in flight.
-        auto fetch = [&](int y, bool with_edge, bool row_ok) -> Raw {
+        // rows are fetched strictly in march order: yf / so_f = next row to fetch and its byte offset from row y0
+        int yf = ystart - DIR;
+        int so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
+        int fidx = -1;                                              // march index of row yf (-1: the row behind the first)
+        auto fetch = [&]() -> Raw {
             Raw w;
-            const int cmin = y <= g.half ? g.cb : 0;
-            const long long off = row_off(g, y) - g.base0;
-            const bool v = row_ok && xin && x >= cmin;
-            w.p = *reinterpret_cast<const vec_t*>(v ? a.pin + off + x : a.zero);
-            if (FUSED) w.r = *reinterpret_cast<const vec_t*>(v ? a.r + off + x : a.zero);
+            const bool own = fidx >= 0 && fidx < nrows;
+            const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
+            const int ve = own ? ve_own : kOob;                    // only centre rows need the element beyond the wave edge
+            w.p = buf_load<vec_t>(rs_p, vo, so_f);
+            if (FUSED) w.r = buf_load<vec_t>(rs_r, vo, so_f);
             else for (int j = 0; j < VEC; ++j) w.r[j] = (T)0;
-            if (XUPD) w.x = *reinterpret_cast<const vec_t*>((v && y >= it.ya && y <= it.yb) ? a.x + off + x : a.zero);
-            const bool ev = row_ok && with_edge && edge && xe >= cmin && xe < g.xlim;
-            w.pe = *(ev ? a.pin + off + xe : a.zero);
-            if (FUSED) w.re = *(ev ? a.r + off + xe : a.zero); else w.re = (T)0;
+            if (XUPD) w.x = buf_load<vec_t>(rs_x, own ? vo : kOob, so_f);
+            w.pe = buf_load<T>(rs_p, ve, so_f);
+            if (FUSED) w.re = buf_load<T>(rs_r, ve, so_f); else w.re = (T)0;
+            if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
+            ++fidx;
             return w;
         };
         auto conv = [&](const Raw& w, vec_t& pn, T& pne) {
@@ -390,34 +459,34 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         vec_t x_c, pold_c;                 // XUPD: x and the input direction of the centre row
         T pne_c, pne_a, dummy;
         {
-            const Raw wb = fetch(ystart - DIR, false, true);
-            const Raw wc = fetch(ystart, true, true);
+            const Raw wb = fetch();
+            const Raw wc = fetch();
 #pragma unroll
-            for (int k = 0; k < DEPTH; ++k) q[k] = fetch(ystart + DIR * (k + 1), true, k + 1 <= nrows);
+            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
             conv(wb, pn_b, dummy);
             conv(wc, pn_c, pne_c);
             r_c = wc.r;
             if (XUPD) { x_c = wc.x; pold_c = wc.p; }
         }
+        // byte offset of the centre row
+        int yc = ystart;
+        int so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
 
         for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
                 const int i = i0 + k;
                 if (i < nrows) {
-                    const int y = ystart + DIR * i;
                     const Raw w = q[k];
-                    q[k] = fetch(ystart + DIR * (i + 1 + DEPTH), true, i + 1 + DEPTH <= nrows);
+                    q[k] = fetch();
                     conv(w, pn_a, pne_a);
 
                     // in-row neighbours: from the adjacent lane, wave-edge lanes use their edge load
-                    T left0 = __shfl_up(pn_c[VEC - 1], 1, kWave);
-                    T rightL = __shfl_down(pn_c[0], 1, kWave);
+                    T left0 = lane_below(pn_c[VEC - 1]);
+                    T rightL = lane_above(pn_c[0]);
                     if (lane == 0) left0 = pne_c;
                     if (lane == kWave - 1) rightL = pne_c;
 
-                    const int cmin = y <= g.half ? g.cb : 0;
-                    const int xint0 = y <= g.half ? g.half + 1 : 1;     // first interior column of row y
                     const vec_t& top = DESC ? pn_b : pn_a;              // row y+1
                     const vec_t& bot = DESC ? pn_a : pn_b;              // row y-1
                     vec_t out;
@@ -432,23 +501,19 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                         v = v + cxk * R;
                         v = v + cyk * top[j];
                         v = v + cyk * bot[j];
-                        const int xj = x + j;
-                        out[j] = (xj >= xint0 && xj <= g.N - 1) ? v : (T)0;
+                        out[j] = in_j[j] ? v : (T)0;
                         dd_acc_prod(acc_pap, (double)c, (double)out[j]);
                         if (MSG) dd_acc_prod(acc_rz, (double)r_c[j], (double)c);
                     }
-                    {   // branch-free stores: lanes outside the stored columns write the trash block
-                        const bool sv = xin && x >= cmin;
-                        const long long off = row_off(g, y) - g.base0 + x;
-                        if (!NOAP) *reinterpret_cast<vec_t*>(sv ? a.ap + off : a.trash) = out;
-                        if (FUSED) *reinterpret_cast<vec_t*>(sv ? a.pout + off : a.trash) = pn_c;
-                        if (XUPD) {
-                            vec_t xn;
+                    if (!NOAP) buf_store(out, rs_ap, vo_own, so_c);
+                    if (FUSED) buf_store(pn_c, rs_po, vo_own, so_c);
+                    if (XUPD) {
+                        vec_t xn;
 #pragma unroll
-                            for (int j = 0; j < VEC; ++j) xn[j] = x_c[j] + alpha_prev * pold_c[j];   // x = x + alpha*z
-                            *reinterpret_cast<vec_t*>(sv ? a.x + off : a.trash) = xn;
-                        }
+                        for (int j = 0; j < VEC; ++j) xn[j] = x_c[j] + alpha_prev * pold_c[j];   // x = x + alpha*z
+                        buf_store(xn, rs_x, vo_own, so_c);
                     }
+                    if (DESC) { so_c -= row_step<T>(g, yc - 1); --yc; } else { so_c += row_step<T>(g, yc); ++yc; }
                     pn_b = pn_c; pn_c = pn_a; pne_c = pne_a; r_c = w.r;
                     if (XUPD) { x_c = w.x; pold_c = w.p; }
                 }
@@ -646,7 +711,6 @@ struct UpdateStArgs {
     const T* p;          // current direction, ghost rows valid
     const T* pprev;      // XM == 2: the previous direction (the other ping-pong buffer)
     T* r; T* x; const T* u;
-    const T* zero; T* trash;
     const double* partA; int nA, strideA, esA;
     double* partB; int strideB, slotB;
     const CgState* s_in; CgState* s_out;
@@ -689,26 +753,42 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     for (int idx = blockIdx.x * kWaves + wave; idx < a.wl.nitems; idx += gridDim.x * kWaves) {
         const Item it = decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx);
         const int x = it.strip * (kWave * VEC) + lane * VEC;
-        const bool xin = x < g.xlim;
-        const bool edge = (lane == 0) || (lane == kWave - 1);
-        const int xe = lane == 0 ? x - 1 : x + VEC;
         const int nrows = it.yb - it.ya + 1;
         const int ystart = DESC ? it.yb : it.ya;
+        const int y0 = it.ya - 1;
+        const long long base_el = row_off(g, y0) - g.base0;
+        const rsrc_t rs_p = make_rsrc(a.p + base_el);
+        const rsrc_t rs_r = make_rsrc(a.r + base_el);
+        const rsrc_t rs_x = make_rsrc(XM != 0 ? a.x + base_el : a.p + base_el);
+        const rsrc_t rs_pp = make_rsrc(XM == 2 ? a.pprev + base_el : a.p + base_el);
+        const rsrc_t rs_u = make_rsrc((FULL && HAS_U) ? a.u + base_el : a.p + base_el);
+        const bool bot_item = it.ya <= g.half;
+        const int vo_own = lane_off<T>(g, x, bot_item);
+        const int ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
+        const int vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);
+        const int vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);
+        const int xint0 = bot_item ? g.half + 1 : 1;
+        bool in_j[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
 
-        // branch-free loads, as in k_stencil.  `own`: the row is one of this item's rows (its r / x / u are needed).
-        auto fetch = [&](int y, bool own, bool row_ok) -> Raw {
+        int yf = ystart - DIR;
+        int so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
+        int fidx = -1;
+        // `own`: the row is one of this item's rows (its r / x / u / previous direction are needed, and its edge element)
+        auto fetch = [&]() -> Raw {
             Raw w;
-            const int cmin = y <= g.half ? g.cb : 0;
-            const long long off = row_off(g, y) - g.base0;
-            const bool v = row_ok && xin && x >= cmin;
-            w.p = *reinterpret_cast<const vec_t*>(v ? a.p + off + x : a.zero);
-            const bool vo = v && own;
-            w.r = *reinterpret_cast<const vec_t*>(vo ? a.r + off + x : a.zero);
-            if (XM != 0) w.x = *reinterpret_cast<const vec_t*>(vo ? a.x + off + x : a.zero);
-            if (XM == 2) w.pp = *reinterpret_cast<const vec_t*>(vo ? a.pprev + off + x : a.zero);
-            if (FULL && HAS_U) w.u = *reinterpret_cast<const vec_t*>(vo ? a.u + off + x : a.zero);
-            const bool ev = row_ok && own && edge && xe >= cmin && xe < g.xlim;
-            w.pe = *(ev ? a.p + off + xe : a.zero);
+            const bool own = fidx >= 0 && fidx < nrows;
+            const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
+            const int vown = own ? vo_own : kOob;
+            w.p = buf_load<vec_t>(rs_p, vo, so_f);
+            w.r = buf_load<vec_t>(rs_r, vown, so_f);
+            if (XM != 0) w.x = buf_load<vec_t>(rs_x, vown, so_f);
+            if (XM == 2) w.pp = buf_load<vec_t>(rs_pp, vown, so_f);
+            if (FULL && HAS_U) w.u = buf_load<vec_t>(rs_u, vown, so_f);
+            w.pe = buf_load<T>(rs_p, own ? ve_own : kOob, so_f);
+            if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
+            ++fidx;
             return w;
         };
 
@@ -716,29 +796,28 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
         vec_t p_b, p_a;
         Raw c;                             // centre row
         {
-            const Raw wb = fetch(ystart - DIR, false, true);
-            c = fetch(ystart, true, true);
+            const Raw wb = fetch();
+            c = fetch();
 #pragma unroll
-            for (int k = 0; k < DEPTH; ++k) q[k] = fetch(ystart + DIR * (k + 1), k + 1 < nrows, k + 1 <= nrows);
+            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
             p_b = wb.p;
         }
+        int yc = ystart;
+        int so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
         for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
                 const int i = i0 + k;
                 if (i < nrows) {
-                    const int y = ystart + DIR * i;
                     const Raw w = q[k];
-                    q[k] = fetch(ystart + DIR * (i + 1 + DEPTH), i + 1 + DEPTH < nrows, i + 1 + DEPTH <= nrows);
+                    q[k] = fetch();
                     p_a = w.p;
 
-                    T left0 = __shfl_up(c.p[VEC - 1], 1, kWave);
-                    T rightL = __shfl_down(c.p[0], 1, kWave);
+                    T left0 = lane_below(c.p[VEC - 1]);
+                    T rightL = lane_above(c.p[0]);
                     if (lane == 0) left0 = c.pe;
                     if (lane == kWave - 1) rightL = c.pe;
 
-                    const int cmin = y <= g.half ? g.cb : 0;
-                    const int xint0 = y <= g.half ? g.half + 1 : 1;
                     const vec_t& top = DESC ? p_b : p_a;
                     const vec_t& bot = DESC ? p_a : p_b;
                     vec_t rn, xn;
@@ -752,8 +831,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                         v = v + cxk * R;
                         v = v + cyk * top[j];
                         v = v + cyk * bot[j];
-                        const int xj = x + j;
-                        const T apj = (xj >= xint0 && xj <= g.N - 1) ? v : (T)0;
+                        const T apj = in_j[j] ? v : (T)0;
                         rn[j] = c.r[j] - alpha * apj;                    // r = r - alpha*A_z      msg_solver.cpp:110-112
                         const double rd = (double)rn[j];
                         dd_acc_prod(s_rr, rd, rd);
@@ -771,12 +849,9 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                             }
                         }
                     }
-                    {
-                        const bool sv = xin && x >= cmin;
-                        const long long off = row_off(g, y) - g.base0 + x;
-                        *reinterpret_cast<vec_t*>(sv ? a.r + off : a.trash) = rn;
-                        if (XM != 0) *reinterpret_cast<vec_t*>(sv ? a.x + off : a.trash) = xn;
-                    }
+                    buf_store(rn, rs_r, vo_own, so_c);
+                    if (XM != 0) buf_store(xn, rs_x, vo_own, so_c);
+                    if (DESC) { so_c -= row_step<T>(g, yc - 1); --yc; } else { so_c += row_step<T>(g, yc); ++yc; }
                     p_b = c.p; c = w;
                 }
             }

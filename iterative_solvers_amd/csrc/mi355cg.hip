@@ -80,7 +80,6 @@ struct mi355cg_ctx {
     double *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
     float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr, *bf = nullptr;
     double* packed = nullptr;           // device scratch, pk_len doubles
-    double *zero_blk = nullptr, *trash_blk = nullptr;   // 256 B each: all-zero source / write-only sink for masked lanes
     double *partA = nullptr, *partB = nullptr, *partR = nullptr;
     double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's record = reduced partials [+ its two boundary rows] (feeds the all-gather)
     int rec_width = 0;
@@ -264,7 +263,6 @@ StencilArgs<T> stencil_args_common(const mi355cg_ctx* c, const StencilWhere& w) 
     StencilArgs<T> a{};
     a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC);
     a.wl = *w.wl;
-    a.zero = reinterpret_cast<const T*>(c->zero_blk); a.trash = reinterpret_cast<T*>(c->trash_blk);
     return a;
 }
 StencilWhere whole_slab(const mi355cg_ctx* c) { return StencilWhere{c->stream, &c->wl, c->grid_stencil, 0}; }
@@ -324,8 +322,7 @@ void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, c
         UpdateStArgs<T> a{};
         a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC); a.wl = *w.wl;
         a.p = p; a.r = r; a.x = x; a.u = u; a.pprev = pprev;
-        a.zero = reinterpret_cast<const T*>(c->zero_blk); a.trash = reinterpret_cast<T*>(c->trash_blk);
-        a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
+            a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
         a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slotA;
         a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = c->update_desc;
         dim3 grid(w.grid), block(kBlock);
@@ -764,7 +761,6 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
         }
     }
     if ((rc = alloc_vec(&c->packed, std::max<long long>(c->pk_len, 1)))) return cleanup();
-    if ((rc = alloc_vec(&c->zero_blk, 32)) || (rc = alloc_vec(&c->trash_blk, 32))) return cleanup();
     if ((rc = alloc_vec(&c->partA, (long long)FA_COUNT * c->strideA))) return cleanup();
     if ((rc = alloc_vec(&c->partB, (long long)FB_COUNT * c->strideB))) return cleanup();
     if ((rc = alloc_vec(&c->partR, 2048))) return cleanup();
@@ -779,6 +775,10 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     }
     hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
     hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
+    // The zero-fills above run on the NULL stream and are asynchronous to the host; the context's own stream is
+    // non-blocking and does not order with them.  Without this wait a delayed memset can land AFTER the first upload
+    // or kernel of the context and wipe it (seen as a right-hand side of zeros -> "converged" at iteration 0).
+    HIPCK(hipDeviceSynchronize());
 
     // problem data on the host in the reference's packed order, then into storage layout on the device
     c->rhs_h.resize(c->pk_len); c->u_h.resize(c->pk_len);
@@ -843,6 +843,10 @@ int mi355cg_create_csr(long long nrows, const int* row_map, const int* entries, 
     }
     hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
     hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
+    // The zero-fills above run on the NULL stream and are asynchronous to the host; the context's own stream is
+    // non-blocking and does not order with them.  Without this wait a delayed memset can land AFTER the first upload
+    // or kernel of the context and wipe it (seen as a right-hand side of zeros -> "converged" at iteration 0).
+    HIPCK(hipDeviceSynchronize());
     c->rhs_h.assign(nrows, 0.0); c->u_h.assign(nrows, 0.0);
     *out = c;
     return MI355CG_OK;
@@ -862,7 +866,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->xf, c->rf, c->pf[0], c->pf[1], c->apf, c->bf,
-                   c->packed, c->zero_blk, c->trash_blk, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
+                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
     for (void* p : dev) if (p) hipFree(p);
     if (c->csr_row_map) hipFree(c->csr_row_map);
     if (c->csr_entries) hipFree(c->csr_entries);

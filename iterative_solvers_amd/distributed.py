@@ -362,6 +362,9 @@ def bench(args, rule: int) -> dict:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "RANK" not in os.environ:                            # started without a launcher: one rank, still through RCCL
+        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+        os.environ.setdefault("MASTER_PORT", "29531")
     if not dist.is_initialized():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n = weak_scaling_n(args.n, world)
