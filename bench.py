@@ -163,7 +163,8 @@ def main():
         alg = KERNEL_ALG_WORDS[dom] * wbytes * U
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         tr = read_traffic()
-        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        kname = {"stencil": "k_stencil", "update": "k_update_st" if recomp else "k_update"}[dom]
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_6290": round(achieved / 6290.0, 4),
                     "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
                     "alg_bytes_per_launch": alg, "alg_words_per_unknown": KERNEL_ALG_WORDS[dom],
@@ -181,8 +182,12 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson {'fp32 inner CG of the mixed-precision path' if f32 else 'fp64'}, matrix-free CG, fixed {args.steps} iterations",
                    "n": n, "unknowns": U, "rule": args.rule, "layout": h.layout()},
+        # SURVEY 8d's convention: 11 words (88 B fp64) per unknown and iteration, the compulsory traffic of textbook
+        # three-phase CG.  This implementation moves fewer words (roofline.words_per_unknown_per_iteration), so the
+        # figure can exceed the 8 TB/s pin rate: it is an algorithmic equivalent, not bytes on the bus -- those are
+        # roofline.moved_gbps_per_iteration and the per-kernel roofline.achieved.
         "hbm_gbps": round(ALG_BYTES_PER_UNKNOWN * (wbytes / 8.0) * U * its / 1e9, 1),
-        "hbm_frac_of_8TBps": round(ALG_BYTES_PER_UNKNOWN * (wbytes / 8.0) * U * its / 1e9 / HBM_PEAK_GBPS, 4),
+        "hbm_gbps_convention": "88 B (fp64) / 44 B (fp32) per unknown per iteration (SURVEY 8d); see roofline.moved_gbps_per_iteration for bytes really moved",
         "roofline": roofline,
     }
     if args.cpu_iters > 0 and not f32:

@@ -402,7 +402,10 @@ def bench(args, rule: int) -> dict:
                    "parallelism": f"row-slab x{world}, RCCL, halo={halo}"},
         "global_iters_per_sec": round(its, 2),
         "hbm_gbps": round(88.0 * U * its / 1e9, 1),
-        "hbm_frac_of_8TBps": round(88.0 * U * its / 1e9 / (8000.0 * world), 4),
+        "hbm_gbps_convention": "88 B per unknown per iteration (SURVEY 8d), summed over GPUs; the default REL_2NORM path really moves 60 B",
+        "moved_gbps_per_gpu": round((60.0 if rule == _capi.RULE_REL_2NORM else 64.0) * U * its / 1e9 / world, 1),
     }
     dist.barrier()
+    if os.environ.get("WORLD_SIZE") is not None and "TORCHELASTIC_RUN_ID" not in os.environ and world == 1:
+        dist.destroy_process_group()                          # started without a launcher: leave nothing behind
     return out

@@ -23,10 +23,9 @@ kt, k = summ("prof_kt")
 fe, f = summ("prof_fetch")
 wr, w = summ("prof_write")
 j = json.load(open(bench))
-xf = j["roofline"].get("alg_words_per_unknown", 6) == 6 and j["roofline"]["kernel"] == "k_stencil"
-words = {"stencil": 6, "update": 3} if xf else {"stencil": 4, "update": 6}
+words = j["roofline"]["alg_words"]
 traffic, lines = {}, []
-for name, key in (("stencil", "k_stencil<fused>"), ("update", "k_update")):
+for name, key in (("stencil", "k_stencil<fused>"), ("update", "k_update_st")):
     rd = f[key]["FETCH_SIZE"] * 1024 * 2          # gfx950: FETCH_SIZE counts 64 B per 128-B request on 16-B/lane streams
     wb = w[key]["WRITE_SIZE"] * 1024
     traffic[name] = rd + wb
@@ -40,14 +39,16 @@ stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_kt", "**", "*kernel_sta
 if stats:
     shutil.copy(sorted(stats)[-1], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
 o = j["roofline"]["other"]
-hdr = f"""Round-1 rocprofv3 summary, default path (REL_2NORM, x update folded into the stencil launch: 9 words/unknown/iteration,
-double-double inner products).  Commands (on the MI355X box, from /tmp with TMPDIR=/tmp, see tools/profile_gpu.sh):
+hdr = f"""Round-1 rocprofv3 summary, default path (REL_2NORM; A p recomputed in the update launch, x updated every second
+iteration: {j['roofline']['words_per_unknown_per_iteration']} words/unknown/iteration; double-double inner products; buffer-resource addressing).
+Commands (on the MI355X box, from /tmp with TMPDIR=/tmp, see tools/profile_gpu.sh):
   rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 300 --warmup 50 --cpu-iters 0 --no-roofline-pass
   rocprofv3 --pmc FETCH_SIZE --output-format csv -- (same)      rocprofv3 --pmc WRITE_SIZE --output-format csv -- (same)
 Workload: N=4096 (U=12 574 721 unknowns), fp64, fixed-iteration CG; 350 iterations per pass.
 Un-profiled bench of the same build on the same box: {j['value']} it/s, {j['ms_per_step']} ms/iteration (profiles/{tag}_bench_n4096.json);
-HIP-event per-launch means in that bench: k_stencil {o['stencil']['avg_ms']} ms, k_update {o['update']['avg_ms']} ms.
-(r01a_* files: the same measurements for the earlier 10-word iteration, stencil 4 words + update 6 words.)
+HIP-event per-launch means in that bench: k_stencil {o['stencil']['avg_ms']} ms, k_update_st {o['update']['avg_ms']} ms
+(k_update_st alternates between 3-word launches on odd iterations and 6-word launches on even ones; the figures are means over both).
+Earlier iterations of the same loop, kept for comparison: r01a_* (10 words: 4 + 6), r01b_* (9 words: 6 + 3, flat update).
 
 == kernel trace (--kernel-trace --stats) ==
 """
