@@ -172,13 +172,14 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     const Geom& g = c->g;
     WorkList dry{}; 
     const long long strip_rows = add_panels(g, vec, g.y_lo, g.y_hi, 0, dry);
-    const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 4096));
+    // 2 048 waves = 2 workgroups per CU: measured best at every size from N = 2048 to 16384 (+4-5 % over 4 096 waves of
+    // half the height at N = 4096 / 8192 / 16384: less halo re-read, and 8 waves per CU already saturate the memory system)
+    const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 2048));
     // Items are dealt to the resident waves round-robin, so the launch takes `rounds` full items per wave -- and one more
-    // if the item count spills over rounds * waves by even a single item (N = 4096 with 24-row items: 4128 items for
-    // 4096 waves, i.e. 32 waves ran twice as long as the rest and the launch waited for them).  Pick the number of
-    // rounds from MAX_ROWS (beyond N = 4096 several rounds of ~24-row items beat one round of taller ones, +5 % at
-    // N = 8192, profiles/r01_tune_notes.md), then the smallest item height whose item count fits into those rounds.
-    const int max_rows = std::max(1, env_int("MI355CG_MAX_ROWS", 24));
+    // if the item count spills over rounds * waves by even a single item.  By default there is ONE round: one item per
+    // wave, as tall as it takes (ty = 50 at N = 4096, 196 at N = 8192); MI355CG_MAX_ROWS caps the height and adds rounds.
+    // The item height is the smallest one whose item count fits into the rounds.
+    const int max_rows = std::max(1, env_int("MI355CG_MAX_ROWS", 1 << 20));
     const long long rounds = std::max<long long>(1, (strip_rows + (long long)target_waves * max_rows - 1) / ((long long)target_waves * max_rows));
     int ty = (int)((strip_rows + rounds * target_waves - 1) / (rounds * target_waves));
     ty = std::max(env_int("MI355CG_MIN_ROWS", 8), ty);
@@ -190,7 +191,7 @@ void build_worklist(mi355cg_ctx* c, int vec) {
         ++ty;
     }
     c->rows_per_item = ty;
-    const int max_blocks = std::max(1, env_int("MI355CG_STENCIL_BLOCKS", 1024));
+    const int max_blocks = std::max(1, env_int("MI355CG_STENCIL_BLOCKS", 512));
     c->grid_stencil = std::max(1, std::min(max_blocks, (c->wl.nitems + kWaves - 1) / kWaves));
     // slab split for halo/compute overlap: edge rows (need the neighbours' ghost rows) and interior rows
     c->wl_edge = WorkList{}; c->wl_int = WorkList{};
@@ -1212,7 +1213,7 @@ int mi355cg_owned_range(mi355cg_handle c, long long* packed_begin, long long* pa
 // The dist entry points enqueue on the caller's stream, taken literally (NULL = HIP's default stream,
 // which is also torch's default stream), so they order with the caller's collectives and copies.
 static hipStream_t pick_stream(mi355cg_ctx*, void* stream) { return (hipStream_t)stream; }
-// Slab-mode iteration config: the 9-word path (x update folded into the stencil) whenever the rule allows it.
+// Slab-mode iteration config: the same launch shapes as mi355cg_solve (7.5 words for REL_2NORM, 8 for MSG).
 static IterCfg dist_cfg(const mi355cg_ctx* c) {
     IterCfg cfg = make_cfg(&c->dist_prm);
     cfg.xfuse = c->xfuse && c->update_mode == 0 && c->dist_prm.rule == MI355CG_RULE_REL_2NORM && !cfg.has_u;
@@ -1361,7 +1362,7 @@ int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, i
     return MI355CG_OK;
 }
 // Call once after the loop (after the last mi355cg_dist_check has been synchronised): applies the x update
-// that is still pending when the 9-word path is active.  No-op otherwise.
+// that is still pending after an odd iteration count (REL_2NORM).  No-op otherwise.
 int mi355cg_dist_finish(mi355cg_handle c, void* stream) {
     if (!c || !c->dist_active) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run");
     const IterCfg cfg = dist_cfg(c);

@@ -341,7 +341,7 @@ class DistributedCG:
                         callback(it, *eng.history(it))
             it_done = res.iterations
         comm.halo_wait(tok_r); comm.halo_wait(tok_p)
-        eng.finish()                                        # flush the x update still pending on the 9-word path
+        eng.finish()                                        # flush the x update still pending after an odd iteration count
         if msg and callback:
             callback(res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm)
         return DistResults(res.iterations, bool(res.converged), res.stop_reason, res.final_residual_norm,
