@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, rule, halo, outdir, eps_kw):
+def _worker(rank, world, port, n, rule, halo, outdir, eps_kw, recompute=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -27,7 +27,7 @@ def _worker(rank, world, port, n, rule, halo, outdir, eps_kw):
         from iterative_solvers_amd.solver import default_params
         from slab_oracle_engine import OracleSlabEngine
         y_lo, y_hi = slab_rows(n, world, rank)
-        eng = OracleSlabEngine(n, y_lo, y_hi)
+        eng = OracleSlabEngine(n, y_lo, y_hi, recompute=recompute)
         cg = DistributedCG(eng, halo=halo)
         p = default_params(rule)
         for k, v in eps_kw.items():
@@ -41,10 +41,10 @@ def _worker(rank, world, port, n, rule, halo, outdir, eps_kw):
         dist.destroy_process_group()
 
 
-def _run(world, n, rule, halo, **eps_kw):
+def _run(world, n, rule, halo, recompute=True, **eps_kw):
     port = 29000 + (os.getpid() * 7 + world * 131 + n) % 2000
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, n, rule, halo, d, eps_kw), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, n, rule, halo, d, eps_kw, recompute), nprocs=world, join=True)
         parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
         parts = [{k: p[k] for k in p.files} for p in parts]
     x = np.concatenate([p["x"] for p in parts])
@@ -55,12 +55,15 @@ def _run(world, n, rule, halo, **eps_kw):
     return x, parts[0]
 
 
-@pytest.mark.parametrize("world,halo", [(2, "gather"), (2, "p2p"), (3, "gather"), (3, "p2p")])
-def test_rel2norm_two_and_three_ranks_match_the_oracle(world, halo):
+# recompute: the update phase rebuilds A p from the direction INCLUDING its ghost rows (the product's default), so the
+# driver has to deliver the direction halo before the update's edge rows; False = the flat update that streams a stored A p
+@pytest.mark.parametrize("world,halo,recompute", [(2, "gather", True), (2, "p2p", True), (3, "gather", True), (3, "p2p", True),
+                                                  (2, "p2p", False), (3, "gather", False)])
+def test_rel2norm_two_and_three_ranks_match_the_oracle(world, halo, recompute):
     from oracle.oracle import OracleGrid
     n = 32
     ref = OracleGrid(n, n).mf_solve(eps=1e-8, max_iterations=10 ** 5)
-    x, r0 = _run(world, n, 1, halo, eps_rel=1e-8, max_iterations=10 ** 5)
+    x, r0 = _run(world, n, 1, halo, recompute=recompute, eps_rel=1e-8, max_iterations=10 ** 5)
     assert int(r0["it"]) == ref.iterations and bool(r0["conv"])
     assert np.abs(x - ref.x).max() <= 1e-10 * np.abs(ref.x).max()
     assert abs(float(r0["rnorm2"]) - ref.r_norm) / ref.initial_r_norm <= 1e-12
