@@ -179,7 +179,9 @@ void build_worklist(mi355cg_ctx* c, int vec) {
     // if the item count spills over rounds * waves by even a single item.  By default there is ONE round: one item per
     // wave, as tall as it takes (ty = 50 at N = 4096, 196 at N = 8192); MI355CG_MAX_ROWS caps the height and adds rounds.
     // The item height is the smallest one whose item count fits into the rounds.
-    const int max_rows = std::max(1, env_int("MI355CG_MAX_ROWS", 1 << 20));
+    // the kernels address an item's rows with 32-bit byte offsets from its first row: (ty + 2) * pitch * 8 must stay below 2^31
+    const int addr_rows = (int)std::min<long long>(1 << 20, 0x7fffffffLL / ((long long)g.Pu * 8) - 70);   // (the fit loop below may add up to 64 rows)
+    const int max_rows = std::max(1, std::min(env_int("MI355CG_MAX_ROWS", 1 << 20), addr_rows));
     const long long rounds = std::max<long long>(1, (strip_rows + (long long)target_waves * max_rows - 1) / ((long long)target_waves * max_rows));
     int ty = (int)((strip_rows + rounds * target_waves - 1) / (rounds * target_waves));
     ty = std::max(env_int("MI355CG_MIN_ROWS", 8), ty);
