@@ -384,6 +384,68 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR item decode
     MI355CG_WT_BEGIN
+    constexpr int DIR = DESC ? -1 : 1;
+    struct Raw { vec_t r, p, x; T re, pe; };
+
+    // ---- per-item addressing state (wave-uniform unless noted) ----
+    int nrows = 0, ystart = 0, y0 = 0, yf = 0, so_f = 0, fidx = 0, yc = 0, so_c = 0;
+    int vo_own = kOob, ve_own = kOob, vo_first = kOob, vo_last = kOob;      // per lane
+    bool in_j[VEC];                                                         // per lane: column is an interior node
+    rsrc_t rs_p, rs_r, rs_x, rs_po, rs_ap;
+    auto setup = [&](int item) {
+        const Item it = decode_item(a.wl, item);
+        const int x = it.strip * (kWave * VEC) + lane * VEC;
+        nrows = it.yb - it.ya + 1;
+        ystart = DESC ? it.yb : it.ya;
+        y0 = it.ya - 1;                                             // lowest row the item touches (halo)
+        const long long base_el = row_off(g, y0) - g.base0;
+        rs_p = make_rsrc(a.pin + base_el);
+        rs_r = make_rsrc(FUSED ? a.r + base_el : a.pin + base_el);
+        rs_x = make_rsrc(XUPD ? a.x + base_el : a.pin + base_el);
+        rs_po = make_rsrc(FUSED ? a.pout + base_el : a.pin + base_el);
+        rs_ap = make_rsrc(NOAP ? a.pin + base_el : a.ap + base_el);
+        const bool bot_item = it.ya <= g.half;                      // all own rows lie in one block of the L
+        vo_own = lane_off<T>(g, x, bot_item);                       // lane offset of the item's own rows (loads and stores)
+        ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
+        vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);       // the halo row behind the first own row
+        vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);   // the halo row ahead of the last one
+        const int xint0 = bot_item ? g.half + 1 : 1;                // first interior column of the own rows
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
+        // rows are fetched strictly in march order: yf / so_f = next row to fetch and its byte offset from row y0
+        yf = ystart - DIR;
+        so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
+        fidx = -1;                                                  // march index of row yf (-1: the row behind the first)
+        yc = ystart;                                                // the centre row and its byte offset
+        so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
+    };
+    auto fetch = [&]() -> Raw {
+        Raw w;
+        const bool own = fidx >= 0 && fidx < nrows;
+        const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
+        const int ve = own ? ve_own : kOob;                        // only centre rows need the element beyond the wave edge
+        w.p = buf_load<vec_t>(rs_p, vo, so_f);
+        if (FUSED) w.r = buf_load<vec_t>(rs_r, vo, so_f);
+        else for (int j = 0; j < VEC; ++j) w.r[j] = (T)0;
+        if (XUPD) w.x = buf_load<vec_t>(rs_x, own ? vo : kOob, so_f);
+        w.pe = buf_load<T>(rs_p, ve, so_f);
+        if (FUSED) w.re = buf_load<T>(rs_r, ve, so_f); else w.re = (T)0;
+        if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
+        ++fidx;
+        return w;
+    };
+
+    // The first item's leading rows are requested BEFORE the prologue: they do not depend on beta, and the state load
+    // and the reduction of the partials (4 us) then run under their latency instead of in front of it.
+    int item = blockIdx.x * kWaves + wave;
+    bool have = item < a.wl.nitems;
+    Raw wb, wc, q[DEPTH];
+    if (have) {
+        setup(item);
+        wb = fetch(); wc = fetch();
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
+    }
 
     T beta = (T)0, alpha_prev = (T)0;
     if (FUSED) {
@@ -401,76 +463,22 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     MI355CG_WT_MID
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd acc_pap = dd_zero(), acc_rz = dd_zero();
-    constexpr int DIR = DESC ? -1 : 1;
-
-    struct Raw { vec_t r, p, x; T re, pe; };
-
-    for (int item = blockIdx.x * kWaves + wave; item < a.wl.nitems; item += gridDim.x * kWaves) {
-        const Item it = decode_item(a.wl, item);
-        const int x = it.strip * (kWave * VEC) + lane * VEC;
-        const int nrows = it.yb - it.ya + 1;
-        const int ystart = DESC ? it.yb : it.ya;
-        const int y0 = it.ya - 1;                                   // lowest row the item touches (halo)
-        const long long base_el = row_off(g, y0) - g.base0;
-        const rsrc_t rs_p = make_rsrc(a.pin + base_el);
-        const rsrc_t rs_r = make_rsrc(FUSED ? a.r + base_el : a.pin + base_el);
-        const rsrc_t rs_x = make_rsrc(XUPD ? a.x + base_el : a.pin + base_el);
-        const rsrc_t rs_po = make_rsrc(FUSED ? a.pout + base_el : a.pin + base_el);
-        const rsrc_t rs_ap = make_rsrc(NOAP ? a.pin + base_el : a.ap + base_el);
-        const bool bot_item = it.ya <= g.half;                      // all own rows lie in one block of the L
-        const int vo_own = lane_off<T>(g, x, bot_item);             // lane offset of the item's own rows (loads and stores)
-        const int ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
-        const int vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);            // the halo row behind the first own row
-        const int vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);     // the halo row ahead of the last one
-        const int xint0 = bot_item ? g.half + 1 : 1;                // first interior column of the own rows
-        bool in_j[VEC];
+    auto conv = [&](const Raw& w, vec_t& pn, T& pne) {
+        if (FUSED) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
+            for (int j = 0; j < VEC; ++j) pn[j] = w.r[j] + beta * w.p[j];     // z = r + beta*z
+            pne = w.re + beta * w.pe;
+        } else { pn = w.p; pne = w.pe; }
+    };
 
-        // rows are fetched strictly in march order: yf / so_f = next row to fetch and its byte offset from row y0
-        int yf = ystart - DIR;
-        int so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
-        int fidx = -1;                                              // march index of row yf (-1: the row behind the first)
-        auto fetch = [&]() -> Raw {
-            Raw w;
-            const bool own = fidx >= 0 && fidx < nrows;
-            const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
-            const int ve = own ? ve_own : kOob;                    // only centre rows need the element beyond the wave edge
-            w.p = buf_load<vec_t>(rs_p, vo, so_f);
-            if (FUSED) w.r = buf_load<vec_t>(rs_r, vo, so_f);
-            else for (int j = 0; j < VEC; ++j) w.r[j] = (T)0;
-            if (XUPD) w.x = buf_load<vec_t>(rs_x, own ? vo : kOob, so_f);
-            w.pe = buf_load<T>(rs_p, ve, so_f);
-            if (FUSED) w.re = buf_load<T>(rs_r, ve, so_f); else w.re = (T)0;
-            if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
-            ++fidx;
-            return w;
-        };
-        auto conv = [&](const Raw& w, vec_t& pn, T& pne) {
-            if (FUSED) {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) pn[j] = w.r[j] + beta * w.p[j];     // z = r + beta*z
-                pne = w.re + beta * w.pe;
-            } else { pn = w.p; pne = w.pe; }
-        };
-
-        Raw q[DEPTH];
+    while (have) {
         vec_t pn_b, pn_c, pn_a, r_c;       // behind / centre / ahead rows in march order
         vec_t x_c, pold_c;                 // XUPD: x and the input direction of the centre row
         T pne_c, pne_a, dummy;
-        {
-            const Raw wb = fetch();
-            const Raw wc = fetch();
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
-            conv(wb, pn_b, dummy);
-            conv(wc, pn_c, pne_c);
-            r_c = wc.r;
-            if (XUPD) { x_c = wc.x; pold_c = wc.p; }
-        }
-        // byte offset of the centre row
-        int yc = ystart;
-        int so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
+        conv(wb, pn_b, dummy);
+        conv(wc, pn_c, pne_c);
+        r_c = wc.r;
+        if (XUPD) { x_c = wc.x; pold_c = wc.p; }
 
         for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
 #pragma unroll
@@ -518,6 +526,14 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                     if (XUPD) { x_c = w.x; pold_c = w.p; }
                 }
             }
+        }
+        item += gridDim.x * kWaves;
+        have = item < a.wl.nitems;
+        if (have) {
+            setup(item);
+            wb = fetch(); wc = fetch();
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
         }
     }
 
@@ -726,6 +742,68 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     MI355CG_WT_BEGIN
+    constexpr bool FULL = XM == 1;
+    constexpr int DIR = DESC ? -1 : 1;
+    struct Raw { vec_t p, r, x, u, pp; T pe; };
+
+    // ---- per-item addressing state, as in k_stencil ----
+    int nrows = 0, ystart = 0, y0 = 0, yf = 0, so_f = 0, fidx = 0, yc = 0, so_c = 0;
+    int vo_own = kOob, ve_own = kOob, vo_first = kOob, vo_last = kOob;
+    bool in_j[VEC];
+    rsrc_t rs_p, rs_r, rs_x, rs_pp, rs_u;
+    auto setup = [&](int idx) {
+        const Item it = decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx);
+        const int x = it.strip * (kWave * VEC) + lane * VEC;
+        nrows = it.yb - it.ya + 1;
+        ystart = DESC ? it.yb : it.ya;
+        y0 = it.ya - 1;
+        const long long base_el = row_off(g, y0) - g.base0;
+        rs_p = make_rsrc(a.p + base_el);
+        rs_r = make_rsrc(a.r + base_el);
+        rs_x = make_rsrc(XM != 0 ? a.x + base_el : a.p + base_el);
+        rs_pp = make_rsrc(XM == 2 ? a.pprev + base_el : a.p + base_el);
+        rs_u = make_rsrc((FULL && HAS_U) ? a.u + base_el : a.p + base_el);
+        const bool bot_item = it.ya <= g.half;
+        vo_own = lane_off<T>(g, x, bot_item);
+        ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
+        vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);
+        vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);
+        const int xint0 = bot_item ? g.half + 1 : 1;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
+        yf = ystart - DIR;
+        so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
+        fidx = -1;
+        yc = ystart;
+        so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
+    };
+    // `own`: the row is one of this item's rows (its r / x / u / previous direction are needed, and its edge element)
+    auto fetch = [&]() -> Raw {
+        Raw w;
+        const bool own = fidx >= 0 && fidx < nrows;
+        const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
+        const int vown = own ? vo_own : kOob;
+        w.p = buf_load<vec_t>(rs_p, vo, so_f);
+        w.r = buf_load<vec_t>(rs_r, vown, so_f);
+        if (XM != 0) w.x = buf_load<vec_t>(rs_x, vown, so_f);
+        if (XM == 2) w.pp = buf_load<vec_t>(rs_pp, vown, so_f);
+        if (FULL && HAS_U) w.u = buf_load<vec_t>(rs_u, vown, so_f);
+        w.pe = buf_load<T>(rs_p, own ? ve_own : kOob, so_f);
+        if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
+        ++fidx;
+        return w;
+    };
+
+    // first item's leading rows requested before the prologue (see k_stencil)
+    int idx = blockIdx.x * kWaves + wave;
+    bool have = idx < a.wl.nitems;
+    Raw wb, c, q[DEPTH];                   // c: centre row
+    if (have) {
+        setup(idx);
+        wb = fetch(); c = fetch();
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
+    }
 
     const StateLite s = load_state_lite(a.s_in);
     if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
@@ -742,68 +820,12 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     const T alpha = (T)alpha_d;
     MI355CG_WT_MID
     const T alpha_prev = (T)s.alpha;       // XM == 2: step length of the previous iteration (0 after init / resume)
-    constexpr bool FULL = XM == 1;
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
     double s_rmax = 0, s_dmax = 0, s_emax = 0;
-    constexpr int DIR = DESC ? -1 : 1;
 
-    struct Raw { vec_t p, r, x, u, pp; T pe; };
-
-    for (int idx = blockIdx.x * kWaves + wave; idx < a.wl.nitems; idx += gridDim.x * kWaves) {
-        const Item it = decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx);
-        const int x = it.strip * (kWave * VEC) + lane * VEC;
-        const int nrows = it.yb - it.ya + 1;
-        const int ystart = DESC ? it.yb : it.ya;
-        const int y0 = it.ya - 1;
-        const long long base_el = row_off(g, y0) - g.base0;
-        const rsrc_t rs_p = make_rsrc(a.p + base_el);
-        const rsrc_t rs_r = make_rsrc(a.r + base_el);
-        const rsrc_t rs_x = make_rsrc(XM != 0 ? a.x + base_el : a.p + base_el);
-        const rsrc_t rs_pp = make_rsrc(XM == 2 ? a.pprev + base_el : a.p + base_el);
-        const rsrc_t rs_u = make_rsrc((FULL && HAS_U) ? a.u + base_el : a.p + base_el);
-        const bool bot_item = it.ya <= g.half;
-        const int vo_own = lane_off<T>(g, x, bot_item);
-        const int ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
-        const int vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);
-        const int vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);
-        const int xint0 = bot_item ? g.half + 1 : 1;
-        bool in_j[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
-
-        int yf = ystart - DIR;
-        int so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
-        int fidx = -1;
-        // `own`: the row is one of this item's rows (its r / x / u / previous direction are needed, and its edge element)
-        auto fetch = [&]() -> Raw {
-            Raw w;
-            const bool own = fidx >= 0 && fidx < nrows;
-            const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
-            const int vown = own ? vo_own : kOob;
-            w.p = buf_load<vec_t>(rs_p, vo, so_f);
-            w.r = buf_load<vec_t>(rs_r, vown, so_f);
-            if (XM != 0) w.x = buf_load<vec_t>(rs_x, vown, so_f);
-            if (XM == 2) w.pp = buf_load<vec_t>(rs_pp, vown, so_f);
-            if (FULL && HAS_U) w.u = buf_load<vec_t>(rs_u, vown, so_f);
-            w.pe = buf_load<T>(rs_p, own ? ve_own : kOob, so_f);
-            if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
-            ++fidx;
-            return w;
-        };
-
-        Raw q[DEPTH];
-        vec_t p_b, p_a;
-        Raw c;                             // centre row
-        {
-            const Raw wb = fetch();
-            c = fetch();
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
-            p_b = wb.p;
-        }
-        int yc = ystart;
-        int so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
+    while (have) {
+        vec_t p_b = wb.p, p_a;
         for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
@@ -855,6 +877,14 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                     p_b = c.p; c = w;
                 }
             }
+        }
+        idx += gridDim.x * kWaves;
+        have = idx < a.wl.nitems;
+        if (have) {
+            setup(idx);
+            wb = fetch(); c = fetch();
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
         }
     }
 
