@@ -162,13 +162,13 @@ int  mi355cg_dist_scatter_ghosts(mi355cg_handle h, int vector /*0 r, 1 current d
 int  mi355cg_dist_stencil(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride,
                           int rows /*0 all, 1 interior, 2 edge rows*/, void *stream);
 int  mi355cg_dist_flip(mi355cg_handle h);          /* once per stencil phase: new direction becomes current */
-/* rows as in mi355cg_dist_stencil.  When mi355cg_dist_update_reads_ghosts() is non-zero (the default 8-word
- * iteration: the update rebuilds A p from the stored direction instead of streaming it) the edge rows read the
- * direction's ghost rows, so those must have arrived before rows 0 / 2 run; otherwise rows 0 / 1 run the flat
- * update over the whole slab and rows 2 is a no-op.                                                          */
+/* rows as in mi355cg_dist_stencil (a full update phase is {0} or {1, 2}).  The default update rebuilds A p from the
+ * stored direction, so its first and last owned row read the direction's ghost rows -- which the stencil launch of a
+ * slab keeps up to date by itself (it recomputes p_new on its halo anyway and stores it there, bit-identical to the
+ * neighbour's rows): the direction never has to cross ranks and mi355cg_dist_update_reads_ghosts() returns 0.        */
 int  mi355cg_dist_update(mi355cg_handle h, const double *gathered_stencil_sums, int nranks, int estride,
                          int rows /*0 all, 1 interior, 2 edge rows*/, void *stream);
-int  mi355cg_dist_update_reads_ghosts(mi355cg_handle h);   /* valid after mi355cg_dist_begin */
+int  mi355cg_dist_update_reads_ghosts(mi355cg_handle h);   /* non-zero: the caller must deliver the direction halo first (never, see above) */
 int  mi355cg_dist_check(mi355cg_handle h, const double *gathered_update_sums, int nranks, int estride, void *stream);
 int  mi355cg_dist_summary(mi355cg_handle h, mi355cg_results *out, int *done);   /* after a stream sync */
 int  mi355cg_dist_finish(mi355cg_handle h, void *stream);   /* once after the loop: flush the pending x update */

@@ -280,6 +280,8 @@ struct StencilArgs {
     HistEntry* hist;
     RuleParams rp;
     int want_diag;
+    int store_ghosts;    // slab mode: also store p_new of the two ghost rows (recomputed from the local ghost copies of r and
+                         // p_old, bit-identical to the neighbour's rows), so the direction never has to cross ranks
 };
 
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     struct Raw { vec_t r, p, x; T re, pe; };
 
     // ---- per-item addressing state (wave-uniform unless noted) ----
-    int nrows = 0, ystart = 0, y0 = 0, yf = 0, so_f = 0, fidx = 0, yc = 0, so_c = 0;
+    int nrows = 0, ystart = 0, y0 = 0, yf = 0, so_f = 0, so_first = 0, fidx = 0, yc = 0, so_c = 0;
     int vo_own = kOob, ve_own = kOob, vo_first = kOob, vo_last = kOob;      // per lane
     bool in_j[VEC];                                                         // per lane: column is an interior node
     rsrc_t rs_p, rs_r, rs_x, rs_po, rs_ap;
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         // rows are fetched strictly in march order: yf / so_f = next row to fetch and its byte offset from row y0
         yf = ystart - DIR;
         so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
+        so_first = so_f;
         fidx = -1;                                                  // march index of row yf (-1: the row behind the first)
         yc = ystart;                                                // the centre row and its byte offset
         so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
@@ -479,6 +482,9 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         conv(wc, pn_c, pne_c);
         r_c = wc.r;
         if (XUPD) { x_c = wc.x; pold_c = wc.p; }
+        // a slab's ghost row (not a physical boundary row): keep the new direction there too
+        auto is_ghost = [&](int yy) { return (yy == g.y_lo - 1 || yy == g.y_hi + 1) && yy >= 1 && yy <= g.N - 1; };
+        if (FUSED && a.store_ghosts && is_ghost(ystart - DIR)) buf_store(pn_b, rs_po, vo_first, so_first);
 
         for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
 #pragma unroll
@@ -527,6 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                 }
             }
         }
+        if (FUSED && a.store_ghosts && is_ghost(yc)) buf_store(pn_c, rs_po, vo_last, so_c);   // yc / so_c / pn_c: the row ahead of the last own row
         item += gridDim.x * kWaves;
         have = item < a.wl.nitems;
         if (have) {

@@ -290,6 +290,7 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
     a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
     a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slotA;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
+    a.store_ghosts = c->is_slab ? 1 : 0;
     if (cfg.recomp && cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) {        // A p is not stored: the update launch recomputes it
         dim3 grid(w.grid), block(kBlock);
         // 2 rows in flight: 4 rows cost a fourth wave per SIMD and measured 9 % slower (profiles/r01_tune_notes.md)
@@ -1349,9 +1350,12 @@ int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, 
     HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
+// Non-zero if the caller has to deliver the direction's ghost rows before the update's edge rows run.  Always 0 now: the
+// stencil launch of a slab keeps the new direction in its two ghost rows itself (StencilArgs::store_ghosts), so the
+// recomputing update finds them locally and the direction never crosses ranks.
 int mi355cg_dist_update_reads_ghosts(mi355cg_handle c) {
-    if (!c || !c->dist_active) return 0;
-    return dist_cfg(c).recomp ? 1 : 0;
+    (void)c;
+    return 0;
 }
 // Asynchronous: after the stream reaches this point the summary is in pinned host memory.
 int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, int estride, void* stream) {

@@ -4,30 +4,20 @@ GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI) for the two things th
 The reference is single-process (no collectives anywhere); this module is the
 scaling surface around the same kernels.  Two ways to move the halo, same kernels:
 
-  halo="gather" (default): ONE collective per phase.  Each rank's record = its reduced partial
-    sums followed by its first and last owned row; `all_gather_into_tensor` makes every record
-    visible; each rank copies its neighbours' rows into its ghost rows (two D2D copies) and its
-    consumer kernel reduces the sums in rank order.  2 collectives + 4 kernel launches per
-    iteration from the host: the cheapest to drive from one Python process per GPU.
-
-        stencil (whole slab) ; flip ; record{(Ap,p),(r,p) | new direction rows} ; all_gather
-        update x, r          ;        record{r.r, max-norms | r rows}           ; all_gather
-
-  halo="p2p": the boundary rows travel as isend/irecv pairs with the two neighbours and overlap
-    compute; the sums use a narrow all-gather.
-
-        stencil (interior rows)      -- overlaps the halo messages still in flight
-        wait halos ; stencil (first + last owned row) ; flip
-        all_gather sums ; isend/irecv new direction rows   -- overlaps the update kernel
-        update x, r
-        all_gather sums ; isend/irecv r rows               -- overlaps the next interior stencil
-
-Each rank reduces the gathered per-rank sums in rank order inside the consumer kernel's
-prologue, so all ranks compute bit-identical alpha/beta and take the same stop decision without
-any host round trip; the host polls a pinned summary every `sync_every` iterations.
-
-`SlabEngine` is the compute side (HIP kernels through the C ABI).  The driver only needs the
-small engine protocol below, which is what the CPU `gloo` tests exercise with a test double.
+  halo="gather" (default): ONE collective per phase.  The update phase's record = the rank's reduced partial
+    sums followed by the first and last owned row of the residual; `all_gather_into_tensor` makes every record
+    visible everywhere and a small kernel copies the two neighbours' rows into the ghost rows.  The stencil
+    phase's record is the sums only (16 doubles).  Per iteration:
+        stencil (whole slab) ; flip ; record{(Ap,p),(r,p)} ; all_gather
+        update x, r          ;        record{r.r, max-norms | r rows} ; all_gather ; scatter ghost rows
+  halo="p2p": the residual's boundary rows travel as isend/irecv pairs with the two neighbours and overlap
+    compute; both phases all-gather 16 doubles per rank.  Per iteration:
+        stencil (interior rows)      -- overlaps the r rows still in flight
+        wait halo ; stencil (first + last owned row) ; flip ; all_gather sums
+        update x, r ; all_gather sums ; isend/irecv r rows    -- overlap the next interior stencil
+  The DIRECTION never crosses ranks: the stencil launch recomputes p_new on its halo anyway (from the ghost copies
+  of r and p_old) and keeps the result in the ghost rows, bit-identical to the neighbour's rows, so the update
+  launch -- which rebuilds A p from p and therefore reads p's ghost rows -- finds them locally.
 """
 from __future__ import annotations
 
@@ -270,18 +260,20 @@ class DistributedCG:
         self.halo = halo
         self.overlap = overlap and halo == "p2p"
         rec = engine.record(0)
-        self.W = rec.numel() if halo == "gather" else engine.rec_header   # doubles all-gathered per rank and phase
-        self.gA = torch.zeros(self.comm.world * self.W, dtype=torch.float64, device=rec.device)
+        self.WA = engine.rec_header                                        # stencil phase: sums only
+        self.W = rec.numel() if halo == "gather" else engine.rec_header   # update phase: sums [+ the residual's boundary rows]
+        self.gA = torch.zeros(self.comm.world * self.WA, dtype=torch.float64, device=rec.device)
         self.gB = torch.zeros(self.comm.world * self.W, dtype=torch.float64, device=rec.device)
 
     def _gather(self, which: int):
+        """All-gather the per-rank sums of a phase.  Only the update phase (which = 1) also moves rows: the residual's
+        boundary rows.  The direction never crosses ranks -- the stencil launch keeps it in the ghost rows itself."""
         eng, comm = self.eng, self.comm
-        if self.halo == "gather":
-            eng.reduce(which, with_rows=True)
-            g = self.gA if which == 0 else self.gB
-            comm.all_gather(g, eng.record(which))
-            if comm.world > 1:                              # stencil records carry the direction, update records carry r
-                eng.scatter_ghosts(1 if which == 0 else 0, g, comm.rank)
+        if which == 1 and self.halo == "gather":
+            eng.reduce(1, with_rows=True)
+            comm.all_gather(self.gB, eng.record(1))
+            if comm.world > 1:
+                eng.scatter_ghosts(0, self.gB, comm.rank)
         else:
             eng.reduce(which, with_rows=False)
             comm.all_gather(self.gA if which == 0 else self.gB, eng.record(which)[:eng.rec_header])
@@ -294,7 +286,6 @@ class DistributedCG:
         eng.begin(params)                                   # x = 0, r = b, p = 0 ; partial norms of r0
         self._gather(1)                                     # (gather mode: also the ghost rows of r0 = b)
         tok_r = comm.halo_start(eng.halo(0)) if p2p else None
-        tok_p = None                                        # direction is 0 everywhere: ghosts already right
         eng.check(self.gB, W)
         res, done = eng.summary()
         if msg and callback:
@@ -303,7 +294,8 @@ class DistributedCG:
         sync_every = min(sync_every, 512)
         every = params.callback_every
         it_done = 0
-        reads_ghosts = eng.update_reads_ghosts              # fixed by begin(): rule + library configuration
+        WA = self.WA
+        assert not eng.update_reads_ghosts                  # the stencil phase keeps the direction's ghost rows itself
         while not done:
             m = min(sync_every, max(1, params.max_iterations - it_done))
             if msg and every > 0:
@@ -311,24 +303,14 @@ class DistributedCG:
             for _ in range(m):
                 if self.overlap and comm.world > 1:
                     eng.stencil(self.gB, W, rows=1)         # interior rows: no ghost needed
-                    comm.halo_wait(tok_r); comm.halo_wait(tok_p)
-                    eng.stencil(self.gB, W, rows=2)         # first + last owned row
+                    comm.halo_wait(tok_r)
+                    eng.stencil(self.gB, W, rows=2)         # first + last owned row (+ the new direction's ghost rows)
                 else:
-                    comm.halo_wait(tok_r); comm.halo_wait(tok_p)
+                    comm.halo_wait(tok_r)
                     eng.stencil(self.gB, W, rows=0)
                 eng.flip()
-                self._gather(0)
-                if p2p:
-                    tok_p = comm.halo_start(eng.halo(1))    # new direction's boundary rows (overlaps the update)
-                if not reads_ghosts:
-                    eng.update(self.gA, W)                  # flat update: streams the stored A p, no ghost row read
-                elif self.overlap and comm.world > 1:
-                    eng.update(self.gA, W, rows=1)          # interior rows recompute A p without a ghost row
-                    comm.halo_wait(tok_p); tok_p = None
-                    eng.update(self.gA, W, rows=2)
-                else:
-                    comm.halo_wait(tok_p); tok_p = None
-                    eng.update(self.gA, W, rows=0)
+                self._gather(0)                             # (Ap, p), (r, p): 16 doubles per rank
+                eng.update(self.gA, WA)                     # A p recomputed from the direction incl. its local ghost rows
                 self._gather(1)
                 if p2p:
                     tok_r = comm.halo_start(eng.halo(0))    # r's boundary rows (overlaps the next interior stencil)
@@ -340,7 +322,7 @@ class DistributedCG:
                     if (it == 1 or (every > 0 and it % every == 0)) and not stopped_here:
                         callback(it, *eng.history(it))
             it_done = res.iterations
-        comm.halo_wait(tok_r); comm.halo_wait(tok_p)
+        comm.halo_wait(tok_r)
         eng.finish()                                        # flush the x update still pending after an odd iteration count
         if msg and callback:
             callback(res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm)

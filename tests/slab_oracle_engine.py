@@ -30,9 +30,11 @@ class _Res:
 
 class OracleSlabEngine:
     def __init__(self, n: int, y_lo: int, y_hi: int, recompute: bool = True):
-        # recompute: the update phase rebuilds A p from the stored direction INCLUDING its ghost rows (k_update_st),
-        # so it only gives the right answer if the driver has moved the direction's boundary rows before it runs
-        self.update_reads_ghosts = recompute
+        # recompute: the update phase rebuilds A p from the stored direction INCLUDING its ghost rows (k_update_st).
+        # The stencil phase keeps the new direction in the ghost rows itself (recomputed from the local ghost copies of r
+        # and the old direction), so the driver never has to move the direction: update_reads_ghosts is False.
+        self.recompute = recompute
+        self.update_reads_ghosts = False
         self.n, self.half, self.y_lo, self.y_hi = n, n // 2, y_lo, y_hi
         self.og = OracleGrid(n, n, 1.0, 2.0, 1.0, 2.0)
         self.U = self.og.size
@@ -174,6 +176,10 @@ class OracleSlabEngine:
             pout[sl] = pn[sl]
             self.ap[sl] = apn[sl]
             acc += (np.dot(apn[sl], pn[sl]), np.dot(self.r[sl], pn[sl]))
+        if rows in (0, 2):                                  # the launch that owns the edge rows also keeps the ghost rows
+            for yg in (self.y_lo - 1, self.y_hi + 1):
+                if 1 <= yg <= self.n - 1:
+                    pout[self.rows(yg, yg)] = pn[self.rows(yg, yg)]
         self.partA[slot] = acc
         if rows in (0, 2):
             self.state = dict(d)
@@ -190,7 +196,7 @@ class OracleSlabEngine:
         for k in range(g.shape[0]):
             pap += g[k, 0]; rz += g[k, 1]
         alpha = (rz / pap) if self.prm.rule == RULE_MSG else (s["rr"] / pap)
-        if not self.update_reads_ghosts:                  # flat update: streams the stored A p, whole slab at once
+        if not self.recompute:                            # flat update: streams the stored A p, whole slab at once
             if rows == 2:
                 return
             o = self.own
