@@ -387,6 +387,10 @@ def bench(args, rule: int) -> dict:
         "hbm_gbps_convention": "88 B per unknown per iteration (SURVEY 8d), summed over GPUs; the default REL_2NORM path really moves 60 B",
         "moved_gbps_per_gpu": round((60.0 if rule == _capi.RULE_REL_2NORM else 64.0) * U * its / 1e9 / world, 1),
     }
+    # whole-iteration roofline per GPU (kernels + collectives + driver); the per-kernel figures are in the 1-GPU bench line
+    moved = out["moved_gbps_per_gpu"]
+    out["roofline"] = {"bound": "hbm", "achieved": moved, "peak": 8000.0, "unit": "GB/s", "frac": round(moved / 8000.0, 4),
+                       "traffic": None, "scope": "bytes one GPU has to move per iteration / wall time per iteration, collectives included"}
     dist.barrier()
     if os.environ.get("WORLD_SIZE") is not None and "TORCHELASTIC_RUN_ID" not in os.environ and world == 1:
         dist.destroy_process_group()                          # started without a launcher: leave nothing behind
