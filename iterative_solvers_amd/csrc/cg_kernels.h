@@ -1,18 +1,19 @@
 // cg_kernels.h -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the matrix-free CG path.
 //
-//   k_stencil  (phase A')  p_new = r + beta*p_old (fused, halo recomputed), Ap = A_h p_new,
-//                          partial sums of (Ap,p) and (r,p).  Replaces MatrixFreeSystem::apply
-//                          (matrix_free_system.cpp:203-340) / KokkosSparse::spmv (msg_solver.cpp:93),
-//                          the direction update (matrix_free_system.cpp:436-438, msg_solver.cpp:167-169)
-//                          and the two dots (matrix_free_system.cpp:417, msg_solver.cpp:96,99).
-//   k_update   (phase B)   x += alpha p, r -= alpha Ap, partial sums/maxes of r.r, |r|, |dx|, |x-u|.
-//                          Replaces matrix_free_system.cpp:422-455 / msg_solver.cpp:105-139.
-//   k_check, k_reduce_parts, k_pack/k_unpack, k_sub, k_resid2: small helpers.
+//   k_stencil   (phase A')  p_new = r + beta*p_old (fused, halo recomputed), A_h p_new evaluated in registers and
+//                           reduced into (Ap,p) [and (r,p)]; A p itself is not stored on the default path.  Replaces
+//                           MatrixFreeSystem::apply (matrix_free_system.cpp:203-340) / KokkosSparse::spmv
+//                           (msg_solver.cpp:93), the direction update (matrix_free_system.cpp:436-438,
+//                           msg_solver.cpp:167-169) and the two dots (matrix_free_system.cpp:417, msg_solver.cpp:96,99).
+//   k_update_st (phase B)   A p rebuilt from three rows of the stored direction, r -= alpha Ap, x update (every second
+//                           iteration, two steps at once; every iteration for the MSG rule), partial sums / maxes of
+//                           r.r, |r|, |dx|, |x-u|.  Replaces matrix_free_system.cpp:422-455 / msg_solver.cpp:105-139.
+//   k_update                flat variant: state initialisation and the fall-back that streams a stored A p.
+//   k_check, k_flush_x, k_make_record, k_scatter_ghosts, k_pack/k_unpack, k_sub, k_resid2, ...: small helpers.
 //
-// Bandwidth-bound stencil: no MFMA.  All arithmetic that the reference does element-wise is
-// done in the reference's operation order without FMA contraction (-ffp-contract=off), so
-// vectors are bit-identical to the CPU oracle for equal scalars; only the inner products use a
-// different (fixed, deterministic) summation tree.
+// Bandwidth-bound: no MFMA.  All arithmetic that the reference does element-wise is done in the reference's
+// operation order without FMA contraction (-ffp-contract=off), so vectors are bit-identical to the CPU oracle for
+// equal scalars; only the inner products differ: they are accumulated as double-double pairs (see dd below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cfloat>
