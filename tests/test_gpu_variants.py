@@ -46,14 +46,14 @@ def _solve(env, n, rule, max_it):
     return res, x, r
 
 
-@pytest.mark.parametrize("n", [6, 64, 130])
+@pytest.mark.parametrize("n", [6, 64, 130, 1026])
 @pytest.mark.parametrize("rule_name", ["rel2", "msg"])
 def test_launch_shapes_take_identical_steps(n, rule_name):
     from iterative_solvers_amd import _capi
     rule = _capi.RULE_REL_2NORM if rule_name == "rel2" else _capi.RULE_MSG_MAXNORM
     ref = None
     for env in VARIANTS:
-        res, x, r = _solve(env, n, rule, 3000)
+        res, x, r = _solve(env, n, rule, 6000)
         if ref is None:
             ref = (res, x, r)
             assert res.converged and res.iterations > 0, (res.iterations, res.converged, res.stop_reason, res.r_norm2, res.initial_r_norm2)
