@@ -36,10 +36,18 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    # Compile to a private file and rename it into place: several processes (torchrun ranks, spawned test workers) may
+    # decide to build at the same moment, and a reader must never see a half-written library.
+    tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
+    cmd = [_hipcc()] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    try:
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
