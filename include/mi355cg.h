@@ -150,6 +150,12 @@ int  mi355cg_get_layout(mi355cg_handle h, long long *padded_len, int *pitch_bott
  * stream, which is torch's default stream too), so they order with the caller's collectives.
  * Host vectors of a slab context (get_rhs, get_solution, ...) cover only its owned packed range. */
 int  mi355cg_slab_rows(int n, int world, int rank, int *y_lo, int *y_hi);
+/* a part of a 2-D decomposition: rows [y_lo, y_hi] x columns [x_lo, x_hi); x-cuts are multiples of 128 (one wave's strip)   */
+int  mi355cg_create_part(int n, int m, double a, double b, double c, double d, int dtype, int device,
+                         int y_lo, int y_hi, int x_lo, int x_hi, mi355cg_handle *out);
+/* out2[0] = sum of v, out2[1] = sum of v^2 over the handle's own cells, accumulated in double-double on the device (the value
+ * does not depend on the decomposition).  which: 0 x, 1 recursive residual, 2 right-hand side, 3 exact solution.             */
+int  mi355cg_checksum(mi355cg_handle h, int which, double *out2);
 int  mi355cg_create_slab(int n, int m, double a, double b, double c, double d, int dtype, int device,
                          int y_lo, int y_hi, mi355cg_handle *out);
 int  mi355cg_owned_range(mi355cg_handle h, long long *packed_begin, long long *packed_len, int *y_lo, int *y_hi);
@@ -177,6 +183,51 @@ int  mi355cg_dist_halo(mi355cg_handle h, int vector /*0 r, 1 current direction*/
                        void **send_lo, void **recv_lo, long long *n_send_lo,
                        void **send_hi, void **recv_hi, long long *n_send_hi);
 int  mi355cg_dist_halo_recv_counts(mi355cg_handle h, long long *n_from_lo, long long *n_from_hi);
+
+/* ---- teams: the native multi-GPU loop (csrc/team.h) ---------------------------------------------------------------
+ * A team = a decomposition of the grid into `world` parts + a transport.  MI355CG_DECOMP_ROWS: row slabs balanced by
+ * unknown count.  MI355CG_DECOMP_2D: (world/2) x 2 blocks -- BASELINE config 4's "2 x 2" for world = 4: y-cuts where the
+ * slabs hold equal unknowns, every slab cut in x where ITS unknowns halve, x-cuts on 128-column strip boundaries.
+ * Per iteration a part exchanges its 16-double record of partial sums twice (all-gather) and the boundary rows / columns
+ * of the residual once (neighbour messages, overlapped with the interior launches on a second stream); results are
+ * bit-identical to the single-GPU solve for every decomposition.  The reference has no counterpart (single process,
+ * solver/solver.hpp:13 HostSpace only); the entry points mirror mi355cg_create / mi355cg_solve.                          */
+#define MI355CG_DECOMP_ROWS 0
+#define MI355CG_DECOMP_2D   1
+typedef struct mi355cg_team_s *mi355cg_team;
+typedef struct mi355cg_halo_msg {
+    int id;          /* position in the global message order (every rank enumerates the same list)     */
+    int peer;        /* the other part                                                                  */
+    int send;        /* 1: this part sends, 0: it receives                                              */
+    int kind;        /* 0: cells [x0, x1) of row y0;  1: column x0 over rows y0..y1                     */
+    int y0, y1, x0, x1;
+    long long count; /* doubles                                                                         */
+} mi355cg_halo_msg;
+/* pure host arithmetic (no GPU needed): the box of `rank`, and its halo messages per iteration */
+int  mi355cg_decompose(int n, int world, int decomp, int rank, int *y_lo, int *y_hi, int *x_lo, int *x_hi);
+int  mi355cg_halo_plan(int n, int world, int decomp, int rank, int max_msgs, int *n_msgs, mi355cg_halo_msg *msgs);
+/* LOCAL transport: this process drives all `world` parts; part r runs on devices[r % ndevices] (NULL: device 0).
+ * Parts on different GPUs need peer access (xGMI).                                                                   */
+int  mi355cg_team_create_local(int n, int m, double a, double b, double c, double d, int world,
+                               const int *devices, int ndevices, int decomp, mi355cg_team *out);
+/* RCCL transport: one process per part.  Rank 0 obtains a 128-byte id (ncclGetUniqueId) and hands it to the others by
+ * any means (MPI, torch.distributed, a file); every rank then creates its side of the team (ncclCommInitRank inside).   */
+int  mi355cg_team_unique_id(void *id128);
+int  mi355cg_team_create_rccl(int n, int m, double a, double b, double c, double d, int world, int rank, int device,
+                              const void *id128, int decomp, mi355cg_team *out);
+void mi355cg_team_destroy(mi355cg_team t);
+/* as mi355cg_solve (no per-iteration diagnostics).  Collective over the team: every rank calls it with the same params.
+ * A stop request on any rank stops all of them at the same iteration (it travels with the next update record).          */
+int  mi355cg_team_solve(mi355cg_team t, const mi355cg_params *params, mi355cg_iter_cb cb, void *user,
+                        const volatile int *stop_flag, mi355cg_results *out);
+int  mi355cg_team_info(mi355cg_team t, int *world, int *nlocal, int *decomp, long long *size);
+int  mi355cg_team_part(mi355cg_team t, int local_index, mi355cg_handle *part, int *rank);
+/* which as in mi355cg_checksum.  get_vector fills the entries of the caller's GLOBAL packed vector (length size) owned by
+ * this process's parts; checksum covers this process's parts.                                                           */
+int  mi355cg_team_get_vector(mi355cg_team t, int which, double *global_packed);
+int  mi355cg_team_checksum(mi355cg_team t, int which, double *out2);
+int  mi355cg_team_set_profiling(mi355cg_team t, int enable);
+int  mi355cg_team_phase_times(mi355cg_team t, double *kernel_ms, double *comm_ms, double *wall_ms);   /* per iteration */
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,12 @@ EXPORTS = [
     "mi355cg_dist_reduce", "mi355cg_dist_sums_ptr", "mi355cg_dist_record_layout", "mi355cg_dist_scatter_ghosts", "mi355cg_dist_stencil", "mi355cg_dist_flip",
     "mi355cg_dist_update", "mi355cg_dist_update_reads_ghosts", "mi355cg_dist_check", "mi355cg_dist_summary", "mi355cg_dist_finish", "mi355cg_dist_history",
     "mi355cg_dist_halo", "mi355cg_dist_halo_recv_counts",
+    "mi355cg_create_part", "mi355cg_checksum", "mi355cg_decompose", "mi355cg_halo_plan",
+    "mi355cg_team_create_local", "mi355cg_team_unique_id", "mi355cg_team_create_rccl", "mi355cg_team_destroy",
+    "mi355cg_team_solve", "mi355cg_team_info", "mi355cg_team_part", "mi355cg_team_get_vector", "mi355cg_team_checksum",
+    "mi355cg_team_set_profiling", "mi355cg_team_phase_times",
 ]
+DECOMP_ROWS, DECOMP_2D = 0, 1
 
 
 class Params(C.Structure):
@@ -42,6 +47,11 @@ class Results(C.Structure):
                 ("final_error_norm", C.c_double), ("r_norm2", C.c_double),
                 ("initial_r_norm2", C.c_double), ("solve_seconds", C.c_double),
                 ("refine_true_rel", C.c_double), ("refine_outer", C.c_int)]
+
+
+class HaloMsg(C.Structure):
+    _fields_ = [("id", C.c_int), ("peer", C.c_int), ("send", C.c_int), ("kind", C.c_int),
+                ("y0", C.c_int), ("y1", C.c_int), ("x0", C.c_int), ("x1", C.c_int), ("count", C.c_longlong)]
 
 
 ITER_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double)
@@ -123,6 +133,22 @@ def load():
     L.mi355cg_dist_history.argtypes = [H, C.c_int, DBP, DBP, DBP]
     L.mi355cg_dist_halo.argtypes = [H, C.c_int, VPP, VPP, LLP, VPP, VPP, LLP]
     L.mi355cg_dist_halo_recv_counts.argtypes = [H, LLP, LLP]
+    L.mi355cg_create_part.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int] * 6 + [C.POINTER(H)]
+    L.mi355cg_checksum.argtypes = [H, C.c_int, DBP]
+    L.mi355cg_decompose.argtypes = [C.c_int] * 4 + [IP] * 4
+    L.mi355cg_halo_plan.argtypes = [C.c_int] * 5 + [IP, C.POINTER(HaloMsg)]
+    L.mi355cg_team_create_local.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int, IP, C.c_int, C.c_int, C.POINTER(H)]
+    L.mi355cg_team_unique_id.argtypes = [C.c_void_p]
+    L.mi355cg_team_create_rccl.argtypes = [C.c_int, C.c_int] + [C.c_double] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(H)]
+    L.mi355cg_team_destroy.argtypes = [H]
+    L.mi355cg_team_destroy.restype = None
+    L.mi355cg_team_solve.argtypes = [H, C.POINTER(Params), ITER_CB, C.c_void_p, C.c_void_p, C.POINTER(Results)]
+    L.mi355cg_team_info.argtypes = [H, IP, IP, IP, LLP]
+    L.mi355cg_team_part.argtypes = [H, C.c_int, C.POINTER(H), IP]
+    L.mi355cg_team_get_vector.argtypes = [H, C.c_int, _DP]
+    L.mi355cg_team_checksum.argtypes = [H, C.c_int, DBP]
+    L.mi355cg_team_set_profiling.argtypes = [H, C.c_int]
+    L.mi355cg_team_phase_times.argtypes = [H, DBP, DBP, DBP]
     _lib = L
     return L
 

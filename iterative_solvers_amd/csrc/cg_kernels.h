@@ -8,7 +8,7 @@
 //   k_update_st (phase B)   A p rebuilt from three rows of the stored direction, r -= alpha Ap, x update (every second
 //                           iteration, two steps at once; every iteration for the MSG rule), partial sums / maxes of
 //                           r.r, |r|, |dx|, |x-u|.  Replaces matrix_free_system.cpp:422-455 / msg_solver.cpp:105-139.
-//   k_update                flat variant: state initialisation and the fall-back that streams a stored A p.
+//   k_update                flat variant: state initialisation, resume step of the mixed-precision path, CSR handles.
 //   k_check, k_flush_x, k_make_record, k_scatter_ghosts, k_pack/k_unpack, k_sub, k_resid2, ...: small helpers.
 //
 // Bandwidth-bound: no MFMA.  All arithmetic that the reference does element-wise is done in the reference's
@@ -25,7 +25,7 @@ constexpr int kBlock = 256;           // threads per workgroup = 4 wave64
 constexpr int kWave = 64;
 constexpr int kWaves = kBlock / kWave;
 constexpr int kHist = 512;            // per-iteration norm history ring (>= sync_every)
-constexpr int kMaxPanels = 6;
+constexpr int kMaxPanels = 8;
 
 // ---- per-wave timing probe (diagnostic build only: -DMI355CG_WAVE_TIMING, tools/wave_timing.py) -------------------
 // Every wave of the two iteration kernels records wall_clock64() (100 MHz) at entry, after the prologue and at exit.
@@ -67,8 +67,10 @@ __host__ __device__ inline bool node_interior(const Geom& g, int x, int y) {
 }
 
 // A panel is a rectangle of owned rows x column strips, cut into row chunks; one (chunk, strip)
-// pair is one work item = one wave marching down `ty` rows of a 64*VEC-column strip.
-struct Panel { int y0, y1, s0, ns, ty, nchunks, item0; };
+// pair is one work item = one wave marching `ty` rows of a 64*VEC-column strip.
+// gc (2-D decomposition): bit 0 = the column left of the panel's first strip belongs to another part (a ghost
+// column of this part), bit 1 = the same on the right of its last strip.
+struct Panel { int y0, y1, s0, ns, ty, nchunks, item0, gc; };
 struct WorkList { Panel p[kMaxPanels]; int np; int nitems; };
 
 // ---- CG state carried on the device ----------------------------------------------------------------
@@ -82,7 +84,7 @@ struct CgState {
     double rmax, dmax, emax, d2, e2;
     int it, done, reason, converged, first, pad_;
 };
-struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2; };
+struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2, tr2; };   // tr2: ||b - A x||_2^2 (REL_2NORM diagnostics mode, written by k_resid2_hist)
 
 // What every wave needs from the state, fetched with SCALAR loads (s_load through the constant address space, one
 // request per scalar cache instead of one per wave).  Copying the whole struct made hipcc fetch half of it with
@@ -243,8 +245,8 @@ __device__ inline void write_state_after_decision(CgState* out, HistEntry* hist,
     o->rmax = d.rmax; o->dmax = d.dmax; o->emax = d.emax; o->d2 = d.d2; o->e2 = d.e2;
     o->done = d.done; o->reason = d.reason; o->converged = d.converged;
     if (hist) {
-        HistEntry h; h.dmax = d.dmax; h.rmax = d.rmax; h.emax = d.emax; h.rnorm2 = d.rnorm2; h.d2 = d.d2; h.e2 = d.e2;
-        hist[s.it % kHist] = h;
+        HistEntry* h = hist + (s.it % kHist);      // field by field: tr2 of this entry belongs to k_resid2_hist
+        h->dmax = d.dmax; h->rmax = d.rmax; h->emax = d.emax; h->rnorm2 = d.rnorm2; h->d2 = d.d2; h->e2 = d.e2;
     }
 }
 
@@ -264,46 +266,35 @@ __device__ inline Decision reduce_and_decide(const StateLite& s, const RuleParam
     }
     return decide_after_update(s, rp, rr, rmax, dmax, emax, d2, e2);
 }
-
 // ---- phase A': fused direction update + 5-point stencil + dots ------------------------------------
 template <typename T>
 struct StencilArgs {
     Geom g;
     WorkList wl;
-    const T* r;          // FUSED: residual (with ghost rows); PLAIN: unused
+    const T* r;          // FUSED: residual (with ghost rows / columns); PLAIN: unused
     const T* pin;        // FUSED: previous direction; PLAIN: the vector to apply the operator to
     T* pout;             // FUSED: new direction (ping-pong partner of pin)
-    T* ap;               // A_h * (new direction | input vector)
-    T* x;                // XUPD: solution vector updated with the previous iteration's step
+    T* ap;               // PLAIN: A_h * input vector
     const double* partB; int nB, strideB, esB;  // update-kernel partials to reduce in the prologue (count, field stride, element stride)
     double* partA; int strideA, slotA;          // this kernel's partials (field-major); first slot of this launch
     const CgState* s_in; CgState* s_out;        // state written by the update kernel / by this kernel
     HistEntry* hist;
     RuleParams rp;
     int want_diag;
-    int store_ghosts;    // slab mode: also store p_new of the two ghost rows (recomputed from the local ghost copies of r and
-                         // p_old, bit-identical to the neighbour's rows), so the direction never has to cross ranks
+    int store_ghosts;    // part of a decomposed grid: also store p_new of the ghost rows (recomputed from the local ghost copies
+                         // of r and p_old, bit-identical to the neighbour's rows), so the direction never has to cross ranks
 };
 
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
 
-// Cache-policy experiment knobs for the update kernel (bit mask, wave-uniform; env MI355CG_NT).
-// Non-temporal accesses on the once-per-iteration streams were measured in the real CG loop
-// (profiles/r01_tune_notes.md): no consistent gain at N = 4096, so the default mask is 0.
-enum { NT_B_X = 1, NT_B_AP = 2, NT_B_P = 16, NT_B_R = 32, NT_B_U = 256 };
-template <typename V> __device__ inline V ld_pol(const V* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
-template <typename V> __device__ inline void st_pol(V* p, V v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
-
 // ---- wave-uniform addressing --------------------------------------------------------------------------------
-// The iteration kernels were instruction-issue bound, not bandwidth bound (SQ counters + tools/wave_timing.py: ~216
-// issued instructions per 128-column row, of which ~60 are the fp64 arithmetic; the SIMDs' issue slots ~100 % busy and
-// the waves dispatched last onto a CU a third slower than the first).  Most of the overhead was 64-bit per-lane address
-// arithmetic and pointer selects.  Here every stream is a buffer resource (base = first row of the item, wave-uniform,
-// in SGPRs), a row is an SGPR byte offset that advances by the row pitch, and the lane contributes ONE 32-bit byte
-// offset that never changes while the item is marched.  A lane that must not touch memory carries an offset beyond
-// num_records: the hardware range check returns 0 for its load and drops its store.  No load or store sits in an
-// exec-masked region, so hipcc waits with counted vmcnt(N) and the rows prefetched for later iterations really stay
-// in flight.  In-row neighbours come through DPP wave shifts, not LDS permutes.
+// Every stream is a buffer resource (base = first row of the work item, wave-uniform, in SGPRs), a row is an SGPR byte
+// offset that advances by the row pitch, and the lane contributes ONE 32-bit byte offset that never changes while the
+// item is marched.  A lane that must not touch memory carries an offset beyond num_records: the hardware range check
+// returns 0 for its load and drops its store.  No load or store sits in an exec-masked region, so hipcc waits with
+// counted vmcnt(N) and the rows prefetched for later steps really stay in flight.  In-row neighbours come through DPP
+// wave shifts, not LDS permutes.  (Round 1: ~120 issued instructions per 128-column row instead of ~216 with flat
+// addressing; profiles/r01_tune_notes.md.)
 constexpr int kOob = (int)0x80000000;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ inline rsrc_t make_rsrc(const void* base) {
@@ -350,11 +341,16 @@ template <typename T, int VEC> __device__ inline int edge_off(const Geom& g, int
     return (edge && xe >= (bottom_row ? g.cb : 0) && xe < g.xlim) ? xe * (int)sizeof(T) : kOob;
 }
 
-// Work-item decode shared by the stencil and the 2-D update kernel.
-struct Item { int strip, ya, yb; };
+// ---- work items ------------------------------------------------------------------------------------------------
+// Items are enumerated panel by panel, chunk-major (strip fastest), and dealt to the resident waves round-robin:
+// wave w takes items w, w + W, w + 2W, ... (W = waves of the launch).  With SHORT items (a few dozen rows) the waves
+// of one round therefore work inside one compact band of rows: at N = 16384 / 32768, where a row is 131 / 262 KB, that
+// keeps concurrent accesses within a few MB per stream and measured +17-18 % over 2 048 independent waves each marching
+// one tall item down the whole grid (tools/hbm_probe.hip, profiles/r02_hbm_probe_*.txt).
+struct Item { int strip, ya, yb, gc; };
 __device__ inline Item decode_item(const WorkList& wl, int item) {
     // constant indices only: a run-time index into the by-value argument struct makes hipcc spill the whole work
-    // list into per-thread LDS (14 KB per block)
+    // list into per-thread LDS
     Panel P = wl.p[0];
 #pragma unroll
     for (int k = 1; k < kMaxPanels; ++k) if (k < wl.np && item >= wl.p[k].item0) P = wl.p[k];
@@ -364,94 +360,124 @@ __device__ inline Item decode_item(const WorkList& wl, int item) {
     it.strip = P.s0 + (local - chunk * P.ns);
     it.ya = P.y0 + chunk * P.ty;
     it.yb = min(P.y1, it.ya + P.ty - 1);
+    it.gc = (it.strip == P.s0 ? (P.gc & 1) : 0) | (it.strip == P.s0 + P.ns - 1 ? (P.gc & 2) : 0);
     return it;
 }
 
-// One wave marches a (64*VEC)-column strip over rows ya..yb, ascending (DESC=false) or
-// descending (DESC=true), keeping three converted rows in registers and DEPTH raw rows in
-// flight.  In-row neighbours come from the adjacent lane (DPP wave shift); the two wave-edge
-// lanes load their outside neighbour themselves.  The update kernel marches the same chunks
-// in the opposite direction, so each kernel starts on the rows the previous one touched last
-// (they are still in the 256 MiB Infinity Cache when the vectors are ~100 MB each).
-// XUPD (relative-2-norm rule only): the x update of the PREVIOUS iteration, x += alpha_{k-1} p_{k-1}, rides
-// along here -- p_{k-1} is this kernel's input direction and is in registers anyway -- so the update kernel
-// shrinks to r -= alpha*Ap (3 words) and an iteration moves 9 words per unknown instead of 10.  Element-wise
-// arithmetic and order are unchanged; the last pending x update is flushed by k_flush_x after the loop.
-// NOAP: A p is only reduced into (Ap, p), not stored -- the update phase recomputes it from the stored direction
-// (k_update_st), which removes one written and one read word per unknown and iteration.
-template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool DESC, bool XUPD = false, bool NOAP = false>
+// Addressing data of one work item, constant while the item is marched (wave-uniform unless noted).  It is computed
+// when the FETCH cursor of a wave enters the item and handed to the COMPUTE cursor when that gets there: the fetch
+// cursor runs DEPTH rows ahead of the compute cursor ACROSS item boundaries, so the load pipeline never drains between
+// items (round 1 refilled it per item, which is what made short items lose there).
+struct ItemAddr {
+    int nrows, ystart;          // rows of the item; its first row in march order
+    long long base_el;          // element offset of row y0 = ya - 1 from the start of a vector
+    int so_first, so_c0;        // byte offsets from row y0 of the halo row behind the first own row / of the first own row
+    int gc; bool bot;
+    int x;                                        // per lane: first column
+    int vo_own, ve_own, vo_first, vo_last;        // per lane: byte offsets within a row (lane_off / edge_off)
+};
+template <typename T, int VEC, bool DESC>
+__device__ inline ItemAddr item_addr(const Geom& g, const Item& it, int lane) {
+    constexpr int DIR = DESC ? -1 : 1;
+    ItemAddr A;
+    A.x = it.strip * (kWave * VEC) + lane * VEC;
+    A.nrows = it.yb - it.ya + 1;
+    A.ystart = DESC ? it.yb : it.ya;
+    const int y0 = it.ya - 1;                                   // lowest row the item touches (halo)
+    A.base_el = row_off(g, y0) - g.base0;
+    A.bot = it.ya <= g.half;                                    // all own rows lie in one block of the L
+    A.vo_own = lane_off<T>(g, A.x, A.bot);                      // the item's own rows (loads and stores)
+    A.ve_own = edge_off<T, VEC>(g, A.x, lane, A.bot);
+    A.vo_first = lane_off<T>(g, A.x, A.ystart - DIR <= g.half); // the halo row behind the first own row
+    A.vo_last = lane_off<T>(g, A.x, A.ystart + DIR * A.nrows <= g.half);   // the halo row ahead of the last one
+    A.so_first = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
+    A.so_c0 = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
+    A.gc = it.gc;
+    return A;
+}
+
+// One wave marches (64*VEC)-column strips: per item the rows ya-1 .. yb+1 pass through a DEPTH-deep queue of raw rows in
+// flight; three converted rows stay in registers (behind / centre / ahead in march order); in-row neighbours come from the
+// adjacent lane (DPP wave shift), the two wave-edge lanes load their outside neighbour themselves.  The role of a
+// dequeued row follows from its index in its item: -1 = halo row behind the first own row, 0 = first centre row,
+// k >= 1 = the row ahead of centre row k-1, whose 5-point formula can now be evaluated.
+// NOAP: A p is only reduced into (Ap, p), not stored -- the update phase recomputes it from the stored direction.
+// GC (2-D decomposition): the strips at the left / right end of this part also store the new direction of the ghost
+// COLUMN beside them (the edge lanes compute it anyway), so the direction never crosses ranks in x either.
+template <typename T, int VEC, bool FUSED, bool MSG, int DEPTH, bool NOAP, bool GC>
 __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "the compute cursor takes its item from the fetch cursor: DEPTH <= rows fetched per item (>= 3)");
     typedef typename VecOf<T, VEC>::type vec_t;
     __shared__ double lds[2 * kWaves];
     const Geom& g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR item decode
+    const int nwaves = gridDim.x * kWaves;
     MI355CG_WT_BEGIN
-    constexpr int DIR = DESC ? -1 : 1;
-    struct Raw { vec_t r, p, x; T re, pe; };
+    struct Raw { vec_t r, p; T re, pe; };
 
-    // ---- per-item addressing state (wave-uniform unless noted) ----
-    int nrows = 0, ystart = 0, y0 = 0, yf = 0, so_f = 0, so_first = 0, fidx = 0, yc = 0, so_c = 0;
-    int vo_own = kOob, ve_own = kOob, vo_first = kOob, vo_last = kOob;      // per lane
-    bool in_j[VEC];                                                         // per lane: column is an interior node
-    rsrc_t rs_p, rs_r, rs_x, rs_po, rs_ap;
-    auto setup = [&](int item) {
-        const Item it = decode_item(a.wl, item);
-        const int x = it.strip * (kWave * VEC) + lane * VEC;
-        nrows = it.yb - it.ya + 1;
-        ystart = DESC ? it.yb : it.ya;
-        y0 = it.ya - 1;                                             // lowest row the item touches (halo)
-        const long long base_el = row_off(g, y0) - g.base0;
-        rs_p = make_rsrc(a.pin + base_el);
-        rs_r = make_rsrc(FUSED ? a.r + base_el : a.pin + base_el);
-        rs_x = make_rsrc(XUPD ? a.x + base_el : a.pin + base_el);
-        rs_po = make_rsrc(FUSED ? a.pout + base_el : a.pin + base_el);
-        rs_ap = make_rsrc(NOAP ? a.pin + base_el : a.ap + base_el);
-        const bool bot_item = it.ya <= g.half;                      // all own rows lie in one block of the L
-        vo_own = lane_off<T>(g, x, bot_item);                       // lane offset of the item's own rows (loads and stores)
-        ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
-        vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);       // the halo row behind the first own row
-        vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);   // the halo row ahead of the last one
-        const int xint0 = bot_item ? g.half + 1 : 1;                // first interior column of the own rows
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
-        // rows are fetched strictly in march order: yf / so_f = next row to fetch and its byte offset from row y0
-        yf = ystart - DIR;
-        so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
-        so_first = so_f;
-        fidx = -1;                                                  // march index of row yf (-1: the row behind the first)
-        yc = ystart;                                                // the centre row and its byte offset
-        so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
+    // ---- fetch cursor ----
+    int f_item = blockIdx.x * kWaves + wave;
+    bool f_have = f_item < a.wl.nitems;
+    ItemAddr F{};
+    int f_idx = 0, f_so = 0, f_y = 0;
+    rsrc_t rs_p = make_rsrc(a.pin), rs_r = make_rsrc(a.pin);
+    auto enter = [&](int item) {
+        F = item_addr<T, VEC, false>(g, decode_item(a.wl, item), lane);
+        rs_p = make_rsrc(a.pin + F.base_el);
+        rs_r = make_rsrc(FUSED ? a.r + F.base_el : a.pin + F.base_el);
+        f_idx = -1; f_so = F.so_first; f_y = F.ystart - 1;
     };
     auto fetch = [&]() -> Raw {
+        if (f_have && f_idx > F.nrows) {                         // lazily: the compute cursor may still need F (see promote)
+            f_item += nwaves; f_have = f_item < a.wl.nitems;
+            if (f_have) enter(f_item);
+        }
+        const bool own = f_idx >= 0 && f_idx < F.nrows;
+        int vo = own ? F.vo_own : (f_idx < 0 ? F.vo_first : F.vo_last);
+        int ve = own ? F.ve_own : kOob;                          // only centre rows need the element beyond the wave edge
+        if (!f_have) { vo = kOob; ve = kOob; }                   // past the last item: the loads touch nothing
         Raw w;
-        const bool own = fidx >= 0 && fidx < nrows;
-        const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
-        const int ve = own ? ve_own : kOob;                        // only centre rows need the element beyond the wave edge
-        w.p = buf_load<vec_t>(rs_p, vo, so_f);
-        if (FUSED) w.r = buf_load<vec_t>(rs_r, vo, so_f);
+        w.p = buf_load<vec_t>(rs_p, vo, f_so);
+        if (FUSED) w.r = buf_load<vec_t>(rs_r, vo, f_so);
         else for (int j = 0; j < VEC; ++j) w.r[j] = (T)0;
-        if (XUPD) w.x = buf_load<vec_t>(rs_x, own ? vo : kOob, so_f);
-        w.pe = buf_load<T>(rs_p, ve, so_f);
-        if (FUSED) w.re = buf_load<T>(rs_r, ve, so_f); else w.re = (T)0;
-        if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
-        ++fidx;
+        w.pe = buf_load<T>(rs_p, ve, f_so);
+        if (FUSED) w.re = buf_load<T>(rs_r, ve, f_so); else w.re = (T)0;
+        f_so += row_step<T>(g, f_y); ++f_y; ++f_idx;
         return w;
     };
 
-    // The first item's leading rows are requested BEFORE the prologue: they do not depend on beta, and the state load
-    // and the reduction of the partials (4 us) then run under their latency instead of in front of it.
-    int item = blockIdx.x * kWaves + wave;
-    bool have = item < a.wl.nitems;
-    Raw wb, wc, q[DEPTH];
-    if (have) {
-        setup(item);
-        wb = fetch(); wc = fetch();
+    // ---- compute cursor ----
+    int c_item = f_item;
+    bool c_have = f_have;
+    ItemAddr C{};
+    int c_idx = -1, c_so = 0, c_y = 0, c_ve_gc = kOob;
+    bool in_j[VEC];
 #pragma unroll
-        for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
-    }
+    for (int j = 0; j < VEC; ++j) in_j[j] = false;
+    rsrc_t rs_po = make_rsrc(a.pin), rs_ap = make_rsrc(a.pin);
+    // The compute cursor enters the item the fetch cursor is in.  That is the right one: when the compute cursor finishes
+    // item i the fetch cursor has fetched 1 .. DEPTH rows beyond it, all of them rows of item i+1 (every item fetches
+    // nrows + 2 >= 3 >= DEPTH rows), and it only moves on to item i+2 at the fetch after the last row of item i+1.
+    auto promote = [&]() {
+        C = F;
+        rs_po = make_rsrc(FUSED ? a.pout + C.base_el : a.pin + C.base_el);
+        rs_ap = make_rsrc(NOAP ? a.pin + C.base_el : a.ap + C.base_el);
+        c_idx = -1; c_so = C.so_c0; c_y = C.ystart;
+        const int xint0 = C.bot ? g.half + 1 : 1;               // first interior column of the own rows
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) in_j[j] = (C.x + j >= xint0) && (C.x + j <= g.N - 1);
+        if (GC) c_ve_gc = ((lane == 0 && (C.gc & 1)) || (lane == kWave - 1 && (C.gc & 2))) ? C.ve_own : kOob;
+    };
 
-    T beta = (T)0, alpha_prev = (T)0;
+    // The first rows are requested BEFORE the prologue: they do not depend on beta, and the state load and the
+    // reduction of the partials then run under their latency instead of in front of it.
+    if (f_have) { enter(f_item); promote(); }
+    Raw q[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
+
+    T beta = (T)0;
     if (FUSED) {
         const StateLite s = load_state_lite(a.s_in);
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
@@ -461,49 +487,42 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, a.s_in, s, d);
         if (d.done) return;
         beta = (T)d.beta;
-        alpha_prev = (T)s.alpha;          // step length of the iteration whose x update is still pending (0 at the start)
     }
 
     MI355CG_WT_MID
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd acc_pap = dd_zero(), acc_rz = dd_zero();
-    auto conv = [&](const Raw& w, vec_t& pn, T& pne) {
-        if (FUSED) {
+    // a part's ghost row (not a physical boundary row): keep the new direction there too
+    auto is_ghost = [&](int yy) { return (yy == g.y_lo - 1 || yy == g.y_hi + 1) && yy >= 1 && yy <= g.N - 1; };
+    vec_t pn_b, pn_c, r_c;                 // behind / centre rows of the new direction, residual of the centre row
+    T pne_c = (T)0;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) pn[j] = w.r[j] + beta * w.p[j];     // z = r + beta*z
-            pne = w.re + beta * w.pe;
-        } else { pn = w.p; pne = w.pe; }
-    };
+    for (int j = 0; j < VEC; ++j) { pn_b[j] = (T)0; pn_c[j] = (T)0; r_c[j] = (T)0; }
 
-    while (have) {
-        vec_t pn_b, pn_c, pn_a, r_c;       // behind / centre / ahead rows in march order
-        vec_t x_c, pold_c;                 // XUPD: x and the input direction of the centre row
-        T pne_c, pne_a, dummy;
-        conv(wb, pn_b, dummy);
-        conv(wc, pn_c, pne_c);
-        r_c = wc.r;
-        if (XUPD) { x_c = wc.x; pold_c = wc.p; }
-        // a slab's ghost row (not a physical boundary row): keep the new direction there too
-        auto is_ghost = [&](int yy) { return (yy == g.y_lo - 1 || yy == g.y_hi + 1) && yy >= 1 && yy <= g.N - 1; };
-        if (FUSED && a.store_ghosts && is_ghost(ystart - DIR)) buf_store(pn_b, rs_po, vo_first, so_first);
-
-        for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
+    while (c_have) {
 #pragma unroll
-            for (int k = 0; k < DEPTH; ++k) {
-                const int i = i0 + k;
-                if (i < nrows) {
-                    const Raw w = q[k];
-                    q[k] = fetch();
-                    conv(w, pn_a, pne_a);
+        for (int k = 0; k < DEPTH; ++k) {
+            if (c_have) {
+                const Raw w = q[k];
+                q[k] = fetch();
+                vec_t pn; T pne;
+                if (FUSED) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) pn[j] = w.r[j] + beta * w.p[j];     // z = r + beta*z
+                    pne = w.re + beta * w.pe;
+                } else { pn = w.p; pne = w.pe; }
 
+                if (c_idx < 0) {                                   // halo row behind the first own row
+                    pn_b = pn;
+                    if (FUSED && a.store_ghosts && is_ghost(C.ystart - 1)) buf_store(pn, rs_po, C.vo_first, C.so_first);
+                } else if (c_idx == 0) {                           // first centre row
+                    pn_c = pn; pne_c = pne; r_c = w.r;
+                } else {                                           // pn = row ahead of centre row c_idx - 1
                     // in-row neighbours: from the adjacent lane, wave-edge lanes use their edge load
                     T left0 = lane_below(pn_c[VEC - 1]);
                     T rightL = lane_above(pn_c[0]);
                     if (lane == 0) left0 = pne_c;
                     if (lane == kWave - 1) rightL = pne_c;
-
-                    const vec_t& top = DESC ? pn_b : pn_a;              // row y+1
-                    const vec_t& bot = DESC ? pn_a : pn_b;              // row y-1
                     vec_t out;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
@@ -514,34 +533,24 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                         T v = cA * c;
                         v = v + cxk * L;
                         v = v + cxk * R;
-                        v = v + cyk * top[j];
-                        v = v + cyk * bot[j];
+                        v = v + cyk * pn[j];                       // row y+1
+                        v = v + cyk * pn_b[j];                     // row y-1
                         out[j] = in_j[j] ? v : (T)0;
                         dd_acc_prod(acc_pap, (double)c, (double)out[j]);
                         if (MSG) dd_acc_prod(acc_rz, (double)r_c[j], (double)c);
                     }
-                    if (!NOAP) buf_store(out, rs_ap, vo_own, so_c);
-                    if (FUSED) buf_store(pn_c, rs_po, vo_own, so_c);
-                    if (XUPD) {
-                        vec_t xn;
-#pragma unroll
-                        for (int j = 0; j < VEC; ++j) xn[j] = x_c[j] + alpha_prev * pold_c[j];   // x = x + alpha*z
-                        buf_store(xn, rs_x, vo_own, so_c);
-                    }
-                    if (DESC) { so_c -= row_step<T>(g, yc - 1); --yc; } else { so_c += row_step<T>(g, yc); ++yc; }
-                    pn_b = pn_c; pn_c = pn_a; pne_c = pne_a; r_c = w.r;
-                    if (XUPD) { x_c = w.x; pold_c = w.p; }
+                    if (!NOAP) buf_store(out, rs_ap, C.vo_own, c_so);
+                    if (FUSED) buf_store(pn_c, rs_po, C.vo_own, c_so);
+                    if (FUSED && GC) buf_store(pne_c, rs_po, c_ve_gc, c_so);   // new direction of the ghost column beside the part
+                    c_so += row_step<T>(g, c_y); ++c_y;
+                    pn_b = pn_c; pn_c = pn; pne_c = pne; r_c = w.r;
                 }
+                if (c_idx == C.nrows) {                            // that was the halo row ahead of the last own row
+                    if (FUSED && a.store_ghosts && is_ghost(c_y)) buf_store(pn, rs_po, C.vo_last, c_so);
+                    c_item += nwaves; c_have = c_item < a.wl.nitems;
+                    if (c_have) promote();
+                } else ++c_idx;
             }
-        }
-        if (FUSED && a.store_ghosts && is_ghost(yc)) buf_store(pn_c, rs_po, vo_last, so_c);   // yc / so_c / pn_c: the row ahead of the last own row
-        item += gridDim.x * kWaves;
-        have = item < a.wl.nitems;
-        if (have) {
-            setup(item);
-            wb = fetch(); wc = fetch();
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
         }
     }
 
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     }
 }
 
-// ---- phase B: fused x / r update + norms -----------------------------------------------------------
+// ---- flat update: state initialisation, resume step of the mixed-precision path, generic CSR path -----------------
 template <typename T>
 struct UpdateArgs {
     long long begin, nvec;     // owned flat range in units of VEC elements (begin is a vec index)
@@ -565,10 +574,7 @@ struct UpdateArgs {
     double* partB; int strideB;
     const CgState* s_in; CgState* s_out;
     int rule;                  // MSG: alpha = rz / Azz ; REL2: alpha = rr / pAp
-    int init;                  // 1: alpha := 0, state initialisation (x = 0, r = b)
-    int reverse;               // flat kernel: sweep the range from its end to its start
-    int nt;                    // NT_B_* cache-policy bits
-    int light;                 // 1: r -= alpha*Ap only (the x update rides in the next stencil launch, see XUPD)
+    int init;                  // 1: alpha := 0, state initialisation (x = 0, r = b); 2: resume (see below)
     double r0norm_resume;      // init == 2 (resume after a residual replacement): the new reference norm
 };
 
@@ -608,8 +614,6 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     const vec_t* __restrict__ Q = reinterpret_cast<const vec_t*>(a.ap);
     const vec_t* __restrict__ Uu = reinterpret_cast<const vec_t*>(a.u);
 
-    const long long last = a.begin + a.nvec - 1;
-    const bool nt_x = a.nt & NT_B_X, nt_ap = a.nt & NT_B_AP, nt_p = a.nt & NT_B_P, nt_r = a.nt & NT_B_R, nt_u = a.nt & NT_B_U;
     auto elem = [&](long long i, const vec_t& x0, const vec_t& pv, const vec_t& r0, const vec_t& qv, const vec_t& uv) {
         vec_t xn, rn;
 #pragma unroll
@@ -628,63 +632,23 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
                 dd_acc_prod(s_e2, ee, ee);
             }
         }
-        st_pol(X + i, xn, nt_x); st_pol(R + i, rn, nt_r);
-    };
-    auto body = [&](long long i_fwd) {
-        const long long i = a.reverse ? last - (i_fwd - a.begin) : i_fwd;
-        const vec_t x0 = ld_pol(X + i, nt_x), pv = ld_pol(Pp + i, nt_p), r0 = ld_pol(R + i, nt_r), qv = ld_pol(Q + i, nt_ap);
-        vec_t uv; if (HAS_U) uv = ld_pol(Uu + i, nt_u);
-        elem(i, x0, pv, r0, qv, uv);
+        X[i] = xn; R[i] = rn;
     };
     long long i = a.begin + (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long end = a.begin + a.nvec;
-    auto at = [&](long long f) { return a.reverse ? last - (f - a.begin) : f; };
-    if (a.light) {
-        // r = r - alpha*A_z only (matrix_free_system.cpp:427-429).  Full groups first: all loads of a group are
-        // issued before any store (no bounds branch inside), so 8 x 16 B per lane are in flight.
-        constexpr int U = 4;
-        for (; i + (U - 1) * stride < end; i += U * stride) {
-            vec_t r0[U], qv[U];
-#pragma unroll
-            for (int k = 0; k < U; ++k) { const long long j = at(i + k * stride); r0[k] = R[j]; qv[k] = Q[j]; }
-            __builtin_amdgcn_sched_barrier(0);      // keep all 2U loads ahead of the arithmetic (hipcc otherwise re-interleaves them)
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                vec_t rn;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    rn[j] = r0[k][j] - alpha * qv[k][j];
-                    const double rd = (double)rn[j];
-                    dd_acc_prod(s_rr, rd, rd);
-                    s_rmax = fmax(s_rmax, fabs(rd));
-                }
-                R[at(i + k * stride)] = rn;
-            }
-        }
-        for (; i < end; i += stride) {
-            const long long j2 = at(i);
-            const vec_t r0 = R[j2], qv = Q[j2];
-            vec_t rn;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                rn[j] = r0[j] - alpha * qv[j];
-                const double rd = (double)rn[j];
-                dd_acc_prod(s_rr, rd, rd);
-                s_rmax = fmax(s_rmax, fabs(rd));
-            }
-            R[j2] = rn;
-        }
-    } else {
-        // two elements per lane and trip: both sets of loads are issued before the first store
-        for (; i + stride < end; i += 2 * stride) {
-            const long long j0 = at(i), j1 = at(i + stride);
-            const vec_t xa = ld_pol(X + j0, nt_x), pa = ld_pol(Pp + j0, nt_p), ra = ld_pol(R + j0, nt_r), qa = ld_pol(Q + j0, nt_ap);
-            const vec_t xb = ld_pol(X + j1, nt_x), pb = ld_pol(Pp + j1, nt_p), rb = ld_pol(R + j1, nt_r), qb = ld_pol(Q + j1, nt_ap);
-            vec_t ua, ub; if (HAS_U) { ua = ld_pol(Uu + j0, nt_u); ub = ld_pol(Uu + j1, nt_u); }
-            elem(j0, xa, pa, ra, qa, ua);
-            elem(j1, xb, pb, rb, qb, ub);
-        }
-        if (i < end) body(i);
+    // two elements per lane and trip: both sets of loads are issued before the first store
+    for (; i + stride < end; i += 2 * stride) {
+        const long long j0 = i, j1 = i + stride;
+        const vec_t xa = X[j0], pa = Pp[j0], ra = R[j0], qa = Q[j0];
+        const vec_t xb = X[j1], pb = Pp[j1], rb = R[j1], qb = Q[j1];
+        vec_t ua, ub; if (HAS_U) { ua = Uu[j0]; ub = Uu[j1]; }
+        elem(j0, xa, pa, ra, qa, ua);
+        elem(j1, xb, pb, rb, qb, ub);
+    }
+    if (i < end) {
+        const vec_t x0 = X[i], pv = Pp[i], r0 = R[i], qv = Q[i];
+        vec_t uv; if (HAS_U) uv = Uu[i];
+        elem(i, x0, pv, r0, qv, uv);
     }
 
     const dd t_rr = block_reduce_dd(s_rr, lds);
@@ -715,15 +679,13 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     }
 }
 
-// ---- phase B, recomputing variant: r -= alpha * (A_h p) with A_h p rebuilt from the stored direction -----------
-// The flat update streams A p back in (one word per unknown) after the stencil launch streamed it out (another
-// word).  This kernel walks the same (chunk, strip) items as the stencil, keeps three rows of p in registers and
-// evaluates the 5-point formula again -- same operands, same operation order, hence the same bits as the values
-// the stencil launch reduced into (Ap, p) -- so A p never touches HBM.  An iteration moves 8 words per unknown
-// (stencil launch: r, p_old, x in; p, x out; this launch: p, r in; r out) instead of 9 (REL_2NORM) or 10 (MSG).
-// XM selects what happens to x in this launch:
+// ---- phase B: r -= alpha * (A_h p) with A_h p rebuilt from the stored direction, x update, norms ----------------
+// This kernel walks the same (chunk, strip) items as the stencil launch -- in the opposite order and direction, so it
+// starts on the rows that launch touched last -- keeps three rows of p in registers and evaluates the 5-point formula
+// again: same operands, same operation order, hence the same bits as the values the stencil launch reduced into
+// (Ap, p).  A p never touches HBM.  XM selects what happens to x in this launch:
 //   0  nothing (odd iterations of the two-step scheme below);
-//   1  x += alpha p plus the MSG norms (|dx|, |x - u|), element-wise identical to k_update;
+//   1  x += alpha p plus the norms |dx|, |x - u| (MSG rule every iteration; REL_2NORM with per-iteration diagnostics);
 //   2  two-step update on even iterations k: x = (x + alpha_{k-1} p_{k-1}) + alpha_k p_k.  p_{k-1} is still intact in the
 //      other direction buffer, alpha_{k-1} is in the state.  Same operations in the same order as two single updates,
 //      but x is read and written once per two iterations: 7.5 words per unknown and iteration on average
@@ -732,7 +694,7 @@ template <typename T>
 struct UpdateStArgs {
     Geom g;
     WorkList wl;
-    const T* p;          // current direction, ghost rows valid
+    const T* p;          // current direction, ghost rows / columns valid
     const T* pprev;      // XM == 2: the previous direction (the other ping-pong buffer)
     T* r; T* x; const T* u;
     const double* partA; int nA, strideA, esA;
@@ -744,74 +706,77 @@ struct UpdateStArgs {
 
 template <typename T, int VEC, int XM, bool HAS_U, int DEPTH, bool DESC>
 __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "see k_stencil");
     typedef typename VecOf<T, VEC>::type vec_t;
     __shared__ double lds[2 * kWaves];
     const Geom& g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int nwaves = gridDim.x * kWaves;
     MI355CG_WT_BEGIN
     constexpr bool FULL = XM == 1;
-    constexpr int DIR = DESC ? -1 : 1;
     struct Raw { vec_t p, r, x, u, pp; T pe; };
 
-    // ---- per-item addressing state, as in k_stencil ----
-    int nrows = 0, ystart = 0, y0 = 0, yf = 0, so_f = 0, fidx = 0, yc = 0, so_c = 0;
-    int vo_own = kOob, ve_own = kOob, vo_first = kOob, vo_last = kOob;
-    bool in_j[VEC];
-    rsrc_t rs_p, rs_r, rs_x, rs_pp, rs_u;
-    auto setup = [&](int idx) {
-        const Item it = decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx);
-        const int x = it.strip * (kWave * VEC) + lane * VEC;
-        nrows = it.yb - it.ya + 1;
-        ystart = DESC ? it.yb : it.ya;
-        y0 = it.ya - 1;
-        const long long base_el = row_off(g, y0) - g.base0;
-        rs_p = make_rsrc(a.p + base_el);
-        rs_r = make_rsrc(a.r + base_el);
-        rs_x = make_rsrc(XM != 0 ? a.x + base_el : a.p + base_el);
-        rs_pp = make_rsrc(XM == 2 ? a.pprev + base_el : a.p + base_el);
-        rs_u = make_rsrc((FULL && HAS_U) ? a.u + base_el : a.p + base_el);
-        const bool bot_item = it.ya <= g.half;
-        vo_own = lane_off<T>(g, x, bot_item);
-        ve_own = edge_off<T, VEC>(g, x, lane, bot_item);
-        vo_first = lane_off<T>(g, x, ystart - DIR <= g.half);
-        vo_last = lane_off<T>(g, x, ystart + DIR * nrows <= g.half);
-        const int xint0 = bot_item ? g.half + 1 : 1;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) in_j[j] = (x + j >= xint0) && (x + j <= g.N - 1);
-        yf = ystart - DIR;
-        so_f = DESC ? (int)((row_off(g, it.yb + 1) - row_off(g, y0)) * (long long)sizeof(T)) : 0;
-        fidx = -1;
-        yc = ystart;
-        so_c = DESC ? (int)((row_off(g, it.yb) - row_off(g, y0)) * (long long)sizeof(T)) : row_step<T>(g, y0);
+    // ---- fetch cursor (see k_stencil) ----
+    int f_item = blockIdx.x * kWaves + wave;
+    bool f_have = f_item < a.wl.nitems;
+    ItemAddr F{};
+    int f_idx = 0, f_so = 0, f_y = 0;
+    rsrc_t rs_p = make_rsrc(a.p), rs_r = rs_p, rs_x = rs_p, rs_pp = rs_p, rs_u = rs_p;
+    auto enter = [&](int idx) {
+        F = item_addr<T, VEC, DESC>(g, decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx), lane);
+        rs_p = make_rsrc(a.p + F.base_el);
+        rs_r = make_rsrc(a.r + F.base_el);
+        rs_x = make_rsrc(XM != 0 ? a.x + F.base_el : a.p + F.base_el);
+        rs_pp = make_rsrc(XM == 2 ? a.pprev + F.base_el : a.p + F.base_el);
+        rs_u = make_rsrc((FULL && HAS_U) ? a.u + F.base_el : a.p + F.base_el);
+        f_idx = -1; f_so = F.so_first; f_y = DESC ? F.ystart + 1 : F.ystart - 1;
     };
     // `own`: the row is one of this item's rows (its r / x / u / previous direction are needed, and its edge element)
     auto fetch = [&]() -> Raw {
+        if (f_have && f_idx > F.nrows) {
+            f_item += nwaves; f_have = f_item < a.wl.nitems;
+            if (f_have) enter(f_item);
+        }
+        const bool own = f_have && f_idx >= 0 && f_idx < F.nrows;
+        int vo = own ? F.vo_own : (f_idx < 0 ? F.vo_first : F.vo_last);
+        if (!f_have) vo = kOob;
+        const int vown = own ? F.vo_own : kOob;
         Raw w;
-        const bool own = fidx >= 0 && fidx < nrows;
-        const int vo = own ? vo_own : (fidx < 0 ? vo_first : (fidx == nrows ? vo_last : kOob));
-        const int vown = own ? vo_own : kOob;
-        w.p = buf_load<vec_t>(rs_p, vo, so_f);
-        w.r = buf_load<vec_t>(rs_r, vown, so_f);
-        if (XM != 0) w.x = buf_load<vec_t>(rs_x, vown, so_f);
-        if (XM == 2) w.pp = buf_load<vec_t>(rs_pp, vown, so_f);
-        if (FULL && HAS_U) w.u = buf_load<vec_t>(rs_u, vown, so_f);
-        w.pe = buf_load<T>(rs_p, own ? ve_own : kOob, so_f);
-        if (DESC) { so_f -= row_step<T>(g, yf - 1); --yf; } else { so_f += row_step<T>(g, yf); ++yf; }
-        ++fidx;
+        w.p = buf_load<vec_t>(rs_p, vo, f_so);
+        w.r = buf_load<vec_t>(rs_r, vown, f_so);
+        if (XM != 0) w.x = buf_load<vec_t>(rs_x, vown, f_so);
+        if (XM == 2) w.pp = buf_load<vec_t>(rs_pp, vown, f_so);
+        if (FULL && HAS_U) w.u = buf_load<vec_t>(rs_u, vown, f_so);
+        w.pe = buf_load<T>(rs_p, own ? F.ve_own : kOob, f_so);
+        if (DESC) { f_so -= row_step<T>(g, f_y - 1); --f_y; } else { f_so += row_step<T>(g, f_y); ++f_y; }
+        ++f_idx;
         return w;
     };
 
-    // first item's leading rows requested before the prologue (see k_stencil)
-    int idx = blockIdx.x * kWaves + wave;
-    bool have = idx < a.wl.nitems;
-    Raw wb, c, q[DEPTH];                   // c: centre row
-    if (have) {
-        setup(idx);
-        wb = fetch(); c = fetch();
+    // ---- compute cursor ----
+    int c_item = f_item;
+    bool c_have = f_have;
+    ItemAddr C{};
+    int c_idx = -1, c_so = 0, c_y = 0;
+    bool in_j[VEC];
 #pragma unroll
-        for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
-    }
+    for (int j = 0; j < VEC; ++j) in_j[j] = false;
+    rsrc_t rs_ro = rs_p, rs_xo = rs_p;
+    auto promote = [&]() {
+        C = F;
+        rs_ro = make_rsrc(a.r + C.base_el);
+        rs_xo = make_rsrc(XM != 0 ? a.x + C.base_el : a.p + C.base_el);
+        c_idx = -1; c_so = C.so_c0; c_y = C.ystart;
+        const int xint0 = C.bot ? g.half + 1 : 1;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) in_j[j] = (C.x + j >= xint0) && (C.x + j <= g.N - 1);
+    };
+
+    if (f_have) { enter(f_item); promote(); }
+    Raw q[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
 
     const StateLite s = load_state_lite(a.s_in);
     if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
@@ -831,25 +796,29 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
     double s_rmax = 0, s_dmax = 0, s_emax = 0;
-
-    while (have) {
-        vec_t p_b = wb.p, p_a;
-        for (int i0 = 0; i0 < nrows; i0 += DEPTH) {
+    vec_t p_b;
+    Raw c;                                 // centre row
 #pragma unroll
-            for (int k = 0; k < DEPTH; ++k) {
-                const int i = i0 + k;
-                if (i < nrows) {
-                    const Raw w = q[k];
-                    q[k] = fetch();
-                    p_a = w.p;
+    for (int j = 0; j < VEC; ++j) { p_b[j] = (T)0; c.p[j] = (T)0; c.r[j] = (T)0; c.x[j] = (T)0; c.u[j] = (T)0; c.pp[j] = (T)0; }
+    c.pe = (T)0;
 
+    while (c_have) {
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            if (c_have) {
+                const Raw w = q[k];
+                q[k] = fetch();
+                if (c_idx < 0) {
+                    p_b = w.p;
+                } else if (c_idx == 0) {
+                    c = w;
+                } else {                                           // w.p = row ahead of the centre row
                     T left0 = lane_below(c.p[VEC - 1]);
                     T rightL = lane_above(c.p[0]);
                     if (lane == 0) left0 = c.pe;
                     if (lane == kWave - 1) rightL = c.pe;
-
-                    const vec_t& top = DESC ? p_b : p_a;
-                    const vec_t& bot = DESC ? p_a : p_b;
+                    const vec_t& top = DESC ? p_b : w.p;           // row y+1
+                    const vec_t& bot = DESC ? w.p : p_b;           // row y-1
                     vec_t rn, xn;
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
@@ -879,20 +848,16 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                             }
                         }
                     }
-                    buf_store(rn, rs_r, vo_own, so_c);
-                    if (XM != 0) buf_store(xn, rs_x, vo_own, so_c);
-                    if (DESC) { so_c -= row_step<T>(g, yc - 1); --yc; } else { so_c += row_step<T>(g, yc); ++yc; }
+                    buf_store(rn, rs_ro, C.vo_own, c_so);
+                    if (XM != 0) buf_store(xn, rs_xo, C.vo_own, c_so);
+                    if (DESC) { c_so -= row_step<T>(g, c_y - 1); --c_y; } else { c_so += row_step<T>(g, c_y); ++c_y; }
                     p_b = c.p; c = w;
                 }
+                if (c_idx == C.nrows) {
+                    c_item += nwaves; c_have = c_item < a.wl.nitems;
+                    if (c_have) promote();
+                } else ++c_idx;
             }
-        }
-        idx += gridDim.x * kWaves;
-        have = idx < a.wl.nitems;
-        if (have) {
-            setup(idx);
-            wb = fetch(); c = fetch();
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
         }
     }
 
@@ -916,113 +881,6 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     }
 }
 
-// 2-D variant of the update: same (chunk, strip) work items as the stencil, marched in the
-// opposite direction (see k_stencil).  Element-wise arithmetic identical to k_update.
-template <typename T>
-struct Update2DArgs {
-    Geom g;
-    WorkList wl;
-    UpdateArgs<T> u;
-};
-
-template <typename T, int VEC, bool HAS_U, int UNROLL, bool DESC>
-__global__ __launch_bounds__(kBlock) void k_update2d(const Update2DArgs<T> aa) {
-    typedef typename VecOf<T, VEC>::type vec_t;
-    __shared__ double lds[2 * kWaves];
-    const UpdateArgs<T>& a = aa.u;
-    const Geom& g = aa.g;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    CgState s;
-    double alpha_d = 0.0, rz = 0.0;
-    if (a.init) {
-        s = CgState{}; s.first = 1; s.it = 0;
-    } else {
-        s = *a.s_in;
-        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) *a.s_out = s; return; }
-        const double pap = dd_value(reduce_parts_dd(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
-        if (a.rule == 0) {
-            rz = dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
-            alpha_d = rz / pap;                       // msg_solver.cpp:102
-        } else {
-            alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419
-        }
-    }
-    const T alpha = (T)alpha_d;
-    dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
-    double s_rmax = 0, s_dmax = 0, s_emax = 0;
-    constexpr int DIR = DESC ? -1 : 1;
-
-    for (int item = blockIdx.x * kWaves + wave; item < aa.wl.nitems; item += gridDim.x * kWaves) {
-        const Item it = decode_item(aa.wl, item);
-        const int x = it.strip * (kWave * VEC) + lane * VEC;
-        const bool xin = x < g.xlim;
-        const int nrows = it.yb - it.ya + 1;
-        const int ystart = DESC ? it.yb : it.ya;
-        for (int i0 = 0; i0 < nrows; i0 += UNROLL) {
-            vec_t x0[UNROLL], pv[UNROLL], r0[UNROLL], qv[UNROLL], uv[UNROLL];
-            long long off[UNROLL];
-            bool ok[UNROLL];
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k) {
-                const int y = ystart + DIR * (i0 + k);
-                ok[k] = (i0 + k < nrows) && xin && x >= (y <= g.half ? g.cb : 0);
-                off[k] = row_off(g, y) - g.base0 + x;
-                if (ok[k]) {
-                    x0[k] = *reinterpret_cast<const vec_t*>(a.x + off[k]);
-                    pv[k] = *reinterpret_cast<const vec_t*>(a.p + off[k]);
-                    r0[k] = *reinterpret_cast<const vec_t*>(a.r + off[k]);
-                    qv[k] = *reinterpret_cast<const vec_t*>(a.ap + off[k]);
-                    if (HAS_U) uv[k] = *reinterpret_cast<const vec_t*>(a.u + off[k]);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < UNROLL; ++k) {
-                if (ok[k]) {
-                    vec_t xn, rn;
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        xn[j] = x0[k][j] + alpha * pv[k][j];        // x = x + alpha*z     msg_solver.cpp:105-107
-                        rn[j] = r0[k][j] - alpha * qv[k][j];        // r = r - alpha*A_z   msg_solver.cpp:110-112
-                        const double rd = (double)rn[j];
-                        dd_acc_prod(s_rr, rd, rd);
-                        s_rmax = fmax(s_rmax, fabs(rd));
-                        const double dx = (double)(xn[j] - x0[k][j]);   // diff = x - x_prev   :124-127
-                        s_dmax = fmax(s_dmax, fabs(dx));
-                        dd_acc_prod(s_d2, dx, dx);
-                        if (HAS_U) {
-                            const double ee = (double)(xn[j] - uv[k][j]);   // error = x - u    :132-136
-                            s_emax = fmax(s_emax, fabs(ee));
-                            dd_acc_prod(s_e2, ee, ee);
-                        }
-                    }
-                    *reinterpret_cast<vec_t*>(a.x + off[k]) = xn;
-                    *reinterpret_cast<vec_t*>(a.r + off[k]) = rn;
-                }
-            }
-        }
-    }
-
-    const dd t_rr = block_reduce_dd(s_rr, lds);
-    const double t_rmax = block_reduce<true>(s_rmax, lds);
-    const double t_dmax = block_reduce<true>(s_dmax, lds);
-    const dd t_d2 = block_reduce_dd(s_d2, lds);
-    double t_emax = 0; dd t_e2 = dd_zero();
-    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce_dd(s_e2, lds); }
-    if (threadIdx.x == 0) {
-        const int b = blockIdx.x, st = a.strideB;
-        a.partB[FB_RR * st + b] = t_rr.hi; a.partB[(FB_RR + FB_LO) * st + b] = t_rr.lo;
-        a.partB[FB_D2 * st + b] = t_d2.hi; a.partB[(FB_D2 + FB_LO) * st + b] = t_d2.lo;
-        a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
-        a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
-        if (blockIdx.x == 0) {
-            CgState o = s;
-            if (!a.init) { o.it = s.it + 1; o.first = 0; o.alpha = alpha_d; o.rz = rz; }
-            *a.s_out = o;
-        }
-    }
-}
-
 // ---- end-of-chunk check: same decision as the next stencil prologue, without advancing -------------
 struct CheckArgs {
     const double* partB; int nB, strideB, esB;
@@ -1040,11 +898,52 @@ __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
     if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, a.s_in, s, d);
 }
 
-// x += alpha * p over the owned range: the x update still pending when an XUPD loop ends.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_flush_x(long long begin, long long len, T* x, const T* p, T alpha) {
-    const long long stride = (long long)gridDim.x * kBlock;
-    for (long long i = begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < begin + len; i += stride) x[i] = x[i] + alpha * p[i];
+// x += alpha * p over the part's own cells (work items): the x update still pending when the two-step loop ends on an odd count.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_flush_x(const Geom g, const WorkList wl, T* x, const T* p, T alpha) {
+    typedef typename VecOf<T, VEC>::type vec_t;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    for (int item = blockIdx.x * kWaves + wave; item < wl.nitems; item += gridDim.x * kWaves) {
+        const Item it = decode_item(wl, item);
+        const int x0 = it.strip * (kWave * VEC) + lane * VEC;
+        if (x0 < (it.ya <= g.half ? g.cb : 0) || x0 >= g.xlim) continue;
+        for (int y = it.ya; y <= it.yb; ++y) {
+            const long long off = row_off(g, y) - g.base0 + x0;
+            const vec_t xv = *reinterpret_cast<const vec_t*>(x + off), pv = *reinterpret_cast<const vec_t*>(p + off);
+            vec_t xn;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) xn[j] = xv[j] + alpha * pv[j];           // x = x + alpha*z
+            *reinterpret_cast<vec_t*>(x + off) = xn;
+        }
+    }
+}
+
+// Deterministic checksums of a vector over the part's own cells: per-block double-double partials of sum(v) and sum(v*v)
+// (fields: 0 sum hi, 1 sum lo, 2 squares hi, 3 squares lo; field stride = gridDim.x).  Lets tests compare decompositions
+// of grids whose vectors are too large to bring to the host.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_checksum(const Geom g, const WorkList wl, const T* v, double* part) {
+    typedef typename VecOf<T, VEC>::type vec_t;
+    __shared__ double lds[2 * kWaves];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    dd s1 = dd_zero(), s2 = dd_zero();
+    for (int item = blockIdx.x * kWaves + wave; item < wl.nitems; item += gridDim.x * kWaves) {
+        const Item it = decode_item(wl, item);
+        const int x0 = it.strip * (kWave * VEC) + lane * VEC;
+        if (x0 < (it.ya <= g.half ? g.cb : 0) || x0 >= g.xlim) continue;
+        for (int y = it.ya; y <= it.yb; ++y) {
+            const vec_t t = *reinterpret_cast<const vec_t*>(v + (row_off(g, y) - g.base0 + x0));
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { s1 = dd_add(s1, dd{(double)t[j], 0.0}); dd_acc_prod(s2, (double)t[j], (double)t[j]); }
+        }
+    }
+    const dd t1 = block_reduce_dd(s1, lds), t2 = block_reduce_dd(s2, lds);
+    if (threadIdx.x == 0) {
+        const int n = gridDim.x, b = blockIdx.x;
+        part[b] = t1.hi; part[n + b] = t1.lo; part[2 * n + b] = t2.hi; part[3 * n + b] = t2.lo;
+    }
 }
 
 // per-block max |x - u| over the owned range (MSG rule: the error norm of an iteration whose update
@@ -1117,28 +1016,35 @@ __global__ __launch_bounds__(kBlock) void k_scatter_ghosts(const ScatterArgs a) 
 }
 
 // ---- packed (reference order) <-> storage layout ---------------------------------------------------
-// Packed index i (relative to the first owned row) of the reference's unknown vector
-// (grid_system.cpp:84-111) <-> node (x, y) <-> storage offset.
-struct PackGeom { Geom g; long long pk_begin, pk_len, bottom_size; };
+// A part's packed order = the reference's unknown order (grid_system.cpp:84-111) restricted to the part's cells: its
+// bottom-block rows, then its upper rows, each row restricted to the part's columns.  For the whole grid and for row
+// slabs that is a contiguous range of the reference's vector.
+struct PackGeom {
+    Geom g;
+    int nb_rows, yb0, xb0, wb;      // bottom-block rows of the part: count, first row, first own column, own columns per row
+    int nu_rows, yu0, xu0, wu;      // upper rows
+    long long pk_len;
+};
 
-__device__ inline long long packed_to_storage(const PackGeom& pg, long long i_global) {
+__device__ inline long long packed_to_storage(const PackGeom& pg, long long i) {
     const Geom& g = pg.g;
+    const long long nb = (long long)pg.nb_rows * pg.wb;
     int x, y;
-    if (i_global < pg.bottom_size) { const int w = g.half - 1; y = (int)(i_global / w) + 1; x = (int)(i_global - (long long)(y - 1) * w) + g.half + 1; }
-    else { const long long j = i_global - pg.bottom_size; const int w = g.N - 1; y = (int)(j / w) + g.half + 1; x = (int)(j - (long long)(y - g.half - 1) * w) + 1; }
+    if (i < nb) { const int k = (int)(i / pg.wb); y = pg.yb0 + k; x = pg.xb0 + (int)(i - (long long)k * pg.wb); }
+    else { const long long j = i - nb; const int k = (int)(j / pg.wu); y = pg.yu0 + k; x = pg.xu0 + (int)(j - (long long)k * pg.wu); }
     return row_off(g, y) - g.base0 + x;
 }
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_unpack(const PackGeom pg, const double* __restrict__ packed, T* __restrict__ storage) {
     const long long stride = (long long)gridDim.x * kBlock;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < pg.pk_len; i += stride)
-        storage[packed_to_storage(pg, pg.pk_begin + i)] = (T)packed[i];
+        storage[packed_to_storage(pg, i)] = (T)packed[i];
 }
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_pack(const PackGeom pg, const T* __restrict__ storage, double* __restrict__ packed) {
     const long long stride = (long long)gridDim.x * kBlock;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < pg.pk_len; i += stride)
-        packed[i] = (double)storage[packed_to_storage(pg, pg.pk_begin + i)];
+        packed[i] = (double)storage[packed_to_storage(pg, i)];
 }
 
 // out = a - b over the owned flat range (true residual A x - b; dirichlet_solver.cpp:156-158)
@@ -1160,6 +1066,14 @@ __global__ __launch_bounds__(kBlock) void k_resid2(long long begin, long long le
     }
     const double t = block_reduce<false>(s, lds);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// REL_2NORM diagnostics mode: fold k_resid2's partials into the history entry of the iteration the state is at
+// (the update launch just advanced it), so the per-iteration true residual needs no host round trip.
+__global__ __launch_bounds__(kBlock) void k_resid2_hist(const double* part, int n, const CgState* s_in, HistEntry* hist) {
+    __shared__ double lds[2 * kWaves];
+    const double t = reduce_parts<false>(part, n, 1, lds);
+    if (threadIdx.x == 0) hist[scalar_load(&s_in->it) % kHist].tr2 = t;
 }
 
 }  // namespace mi355cg

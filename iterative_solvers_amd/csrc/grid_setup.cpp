@@ -37,10 +37,11 @@ inline bool is_bottom(const GridParams& g, int x, int y) {        // :38-43
     return (y == 0 && (x >= g.n / 2 && x <= g.n)) || (y == g.m / 2 && (x >= 0 && x <= g.n / 2));
 }
 
-void fill_row(const GridParams& g, int y, double* rhs, double* u, double* xs, double* ys) {
-    const int x0 = y <= g.half ? g.half + 1 : 1;
+// interior columns of row y inside [xa, xb); outputs start at the first of them
+void fill_row(const GridParams& g, int y, int xa, int xb, double* rhs, double* u, double* xs, double* ys) {
+    const int x0 = std::max(xa, y <= g.half ? g.half + 1 : 1), x1 = std::min(xb, g.n);
     const double yp = g.c + y * g.y_step;                          // calculate_y :74-77
-    for (int x = x0; x < g.n; ++x) {
+    for (int x = x0; x < x1; ++x) {
         const int i = x - x0;
         const double xp = g.a + x * g.x_step;                      // calculate_x :69-72
         if (xs) xs[i] = xp;
@@ -61,16 +62,25 @@ void fill_row(const GridParams& g, int y, double* rhs, double* u, double* xs, do
 
 void grid_fill_rows(const GridParams& g, int y_begin, int y_end,
                     double* rhs, double* u_true, double* xs, double* ys) {
+    grid_fill_box(g, y_begin, y_end, 0, g.n, rhs, u_true, xs, ys);
+}
+
+void grid_fill_box(const GridParams& g, int y_begin, int y_end, int x_begin, int x_end,
+                   double* rhs, double* u_true, double* xs, double* ys) {
     if (y_end < y_begin) return;
-    const long long base = packed_row_begin(g, y_begin);
     const int rows = y_end - y_begin + 1;
+    // own columns per bottom-block / upper row, and where each row starts in the part's packed order
+    const long long wb = std::max(0, std::min(x_end, g.n) - std::max(x_begin, g.half + 1));
+    const long long wu = std::max(0, std::min(x_end, g.n) - std::max(x_begin, 1));
+    const long long nb = std::max(0, std::min(y_end, g.half) - y_begin + 1);
+    auto row_begin = [&](int y) { return y <= g.half ? (long long)(y - y_begin) * wb : nb * wb + (long long)(y - std::max(y_begin, g.half + 1)) * wu; };
     unsigned hw = std::thread::hardware_concurrency();
     int nthreads = (int)std::min<long long>(hw ? hw : 1, std::max<long long>(1, (long long)rows * g.n / 65536));
     nthreads = std::max(1, std::min(nthreads, 64));
     auto work = [&](int t) {
         for (int y = y_begin + t; y <= y_end; y += nthreads) {
-            const long long off = packed_row_begin(g, y) - base;
-            fill_row(g, y, rhs ? rhs + off : nullptr, u_true ? u_true + off : nullptr,
+            const long long off = row_begin(y);
+            fill_row(g, y, x_begin, x_end, rhs ? rhs + off : nullptr, u_true ? u_true + off : nullptr,
                      xs ? xs + off : nullptr, ys ? ys + off : nullptr);
         }
     };

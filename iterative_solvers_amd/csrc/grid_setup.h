@@ -39,4 +39,9 @@ inline long long packed_row_begin(const GridParams& g, int y) {
 void grid_fill_rows(const GridParams& g, int y_begin, int y_end,
                     double* rhs, double* u_true, double* xs, double* ys);
 
+// The same for one part of a decomposed grid: rows y_begin..y_end, each restricted to the interior columns inside
+// [x_begin, x_end); outputs in the part's packed order (its bottom-block rows, then its upper rows).
+void grid_fill_box(const GridParams& g, int y_begin, int y_end, int x_begin, int x_end,
+                   double* rhs, double* u_true, double* xs, double* ys);
+
 }  // namespace mi355cg

@@ -1,5 +1,6 @@
 // mi355cg.hip -- C ABI (include/mi355cg.h) over the HIP kernels in cg_kernels.h.
-// One context = one GPU = one slab of grid rows (the whole grid on a single GPU).
+// One context = one GPU = one part of the grid (the whole grid on a single GPU; a row slab or a 2-D block of a
+// decomposed grid).  Teams of parts (native multi-GPU loop, RCCL / in-process transports) live in team.h.
 // No CPU fallback: every compute entry point needs a working HIP device.
 #include "../../include/mi355cg.h"
 #include "cg_kernels.h"
@@ -42,7 +43,8 @@ int env_int(const char* name, int dflt) {
 
 inline long long round_up(long long v, long long m) { return (v + m - 1) / m * m; }
 
-constexpr int kRecHeader = 16;     // doubles reserved for the sums (hi/lo pairs) and maxes at the head of a slab record
+constexpr int kRecHeader = 16;     // doubles reserved for the sums (hi/lo pairs) and maxes at the head of a part's record
+constexpr int kStripCols = 128;    // fp64 strip = 64 lanes x double2: the unit of the x-cuts of a 2-D decomposition
 
 struct EventPool {
     std::vector<hipEvent_t> ev;
@@ -55,6 +57,9 @@ struct EventPool {
     void destroy() { for (auto e : ev) hipEventDestroy(e); ev.clear(); used = 0; }
 };
 
+// One launch shape: the work items of a set of rows x strips and the persistent grid that marches them.
+struct Plan { WorkList wl{}; int grid = 0; int ty = 0; };
+
 }  // namespace
 
 struct mi355cg_ctx {
@@ -63,22 +68,21 @@ struct mi355cg_ctx {
     hipStream_t stream = nullptr;
     GridParams gp;
     Geom g{};
+    int s_lo = 0, s_hi = 0;             // owned fp64 strips [s_lo, s_hi) (kStripCols columns each); all of them unless 2-D
     long long storage_len = 0;          // elements per vector incl. ghost rows
-    long long pk_begin = 0, pk_len = 0; // owned packed range
-    WorkList wl{}, wl_int{}, wl_edge{};   // whole slab; interior rows; first+last owned row
-    int grid_int = 0, grid_edge = 0;
-    int grid_stencil = 0, grid_update = 0, rows_per_item = 0, depth = 4;
-    int update_mode = 1, stencil_desc = 1, update_desc = 0, update_unroll = 4;   // launch-shape knobs (env)
-    int nt_mask = 0;                    // cache-policy bits (NT_*), env MI355CG_NT
-    int xfuse = 1, xdepth = 2;          // REL_2NORM: fold the x update into the next stencil launch (env MI355CG_XFUSE, MI355CG_XDEPTH)
-    int recompute = 1, udepth = 2, udepth_full = 2, msg_depth = 2, x2step = 1, sdepth = 2;      // update phase rebuilds A p from the stored direction instead of streaming it (env MI355CG_RECOMPUTE, MI355CG_UDEPTH)
+    long long pk_begin = 0, pk_len = 0; // owned cells in the part's packed order (pk_begin: global packed index of the first; row slabs are contiguous)
+    PackGeom pg{};
+    Plan whole, interior, edge;         // whole part; rows / strips that need no ghost data; the rest (first + last row, edge strips)
+    Plan whole32;                       // fp32 kernels (VEC = 4, 256-column strips), single GPU only
+    int depth = 2;                      // raw rows in flight per wave (env MI355CG_DEPTH: 2 or 3)
+    bool has_gc = false;                // 2-D part with a neighbour in x: the stencil launches keep the ghost columns of the direction
     int nB_own = 0;                     // partB slots written by the last update-phase launch(es) of this context
     int strideA = 0, strideB = 0;
-    struct Plan { WorkList wl; int grid_stencil = 0, grid_update = 0, rows_per_item = 0; } plan32;   // fp32 kernels (VEC = 4)
 
     // device vectors in storage layout (fp64 set always; fp32 set for F32_MIXED)
     double *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
-    float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr, *bf = nullptr;
+    double* scratch[2] = {nullptr, nullptr};      // mi355cg_apply / true residual work space, allocated on first use: never a solver vector
+    float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr;
     double* packed = nullptr;           // device scratch, pk_len doubles
     double *partA = nullptr, *partB = nullptr, *partR = nullptr;
     double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's record = reduced partials [+ its two boundary rows] (feeds the all-gather)
@@ -91,13 +95,13 @@ struct mi355cg_ctx {
     HistEntry* hist_h = nullptr;        // pinned
     double* partR_h = nullptr;          // pinned
 
-    std::vector<double> rhs_h, u_h;     // packed host copies (owned range)
+    std::vector<double> rhs_h, u_h;     // host copies (owned cells, the part's packed order)
     bool have_u_dev = false, solved = false;
     // generic CSR handle (mi355cg_create_csr): vectors are plain length-n arrays, the operator is this matrix
     bool is_csr = false;
     long long csr_n = 0, csr_nnz = 0;
     int *csr_row_map = nullptr, *csr_entries = nullptr; double* csr_values = nullptr;
-    int grid_csr = 0;
+    int grid_csr = 0, grid_update = 0;
     int cur = 0;                        // p[cur] holds the current direction after the last stencil
     int nA_dist = 0;                    // slab mode: stencil partial slots written by the last stencil phase
 
@@ -118,6 +122,15 @@ namespace {
 // ---- layout ----------------------------------------------------------------------------------------
 long long phys_start(const Geom& g, int y) { return row_off(g, y) + (y <= g.half ? g.cb : 0); }
 long long phys_end(const Geom& g, int y) { return phys_start(g, y) + (y <= g.half ? g.Pb : g.Pu); }
+int strips_total(const GridParams& gp, int vec) { return (gp.n - 1) / (kWave * vec) + 1; }
+int first_bottom_strip(const GridParams& gp, int vec) { return (gp.half + 1) / (kWave * vec); }
+
+// first / one-past-last interior column of row y inside the part's strips
+void own_cols(const mi355cg_ctx* c, int y, int* xa, int* xb) {
+    const int lo = y <= c->gp.half ? c->gp.half + 1 : 1, hi = c->gp.n;       // interior columns [lo, hi)
+    *xa = std::max(lo, c->s_lo * kStripCols);
+    *xb = std::max(*xa, std::min(hi, c->s_hi * kStripCols));
+}
 
 void build_geom(mi355cg_ctx* c, int vec, int y_lo, int y_hi) {
     Geom& g = c->g;
@@ -134,243 +147,219 @@ void build_geom(mi355cg_ctx* c, int vec, int y_lo, int y_hi) {
     g.own_begin = phys_start(g, y_lo) - g.base0;
     g.own_len = phys_end(g, y_hi) - phys_start(g, y_lo);
     g.A = gp.A; g.xk = gp.x_k; g.yk = gp.y_k;
-    c->pk_begin = packed_row_begin(gp, y_lo);
-    c->pk_len = (y_hi + 1 <= gp.n - 1 ? packed_row_begin(gp, y_hi + 1) : gp.size) - c->pk_begin;
+    // the part's packed order: its bottom-block rows (each restricted to the own columns), then its upper rows
+    PackGeom& pg = c->pg;
+    pg.g = g;
+    const int yb0 = y_lo, yb1 = std::min(y_hi, gp.half), yu0 = std::max(y_lo, gp.half + 1), yu1 = y_hi;
+    int xa = 0, xb = 0;
+    pg.nb_rows = std::max(0, yb1 - yb0 + 1); pg.yb0 = yb0;
+    own_cols(c, gp.half, &xa, &xb); pg.xb0 = xa; pg.wb = pg.nb_rows ? xb - xa : 0;
+    pg.nu_rows = std::max(0, yu1 - yu0 + 1); pg.yu0 = yu0;
+    own_cols(c, gp.half + 1, &xa, &xb); pg.xu0 = xa; pg.wu = pg.nu_rows ? xb - xa : 0;
+    pg.pk_len = (long long)pg.nb_rows * pg.wb + (long long)pg.nu_rows * pg.wu;
+    c->pk_len = pg.pk_len;
+    c->pk_begin = packed_row_begin(gp, y_lo);        // meaningful for row slabs (contiguous global range)
 }
 
-// Cut rows [ya, yb] into (chunk, strip) items: one wave marches `ty` rows of a 64*vec-column strip.
-// Appends up to two panels (bottom-right block rows, upper block rows); returns the strip-rows added.
-long long add_panels(const Geom& g, int vec, int ya, int yb, int ty, WorkList& wl) {
-    const int sw = kWave * vec;
-    const int ns_all = (g.N - 1) / sw + 1;
-    struct Rect { int y0, y1, s0, ns; } rects[2];
+// Rows [ya, yb] x strips [sa, sb) as up to two rectangles (bottom-right block rows, upper block rows) with their
+// ghost-column flags (bit 0: a part to the left, bit 1: a part to the right).
+struct Rect { int y0, y1, s0, s1, gc; };
+int region_rects(const GridParams& gp, int vec, int ya, int yb, int sa, int sb, Rect out[2]) {
+    const int ns_all = strips_total(gp, vec), s0b = first_bottom_strip(gp, vec);
     int nr = 0;
-    if (ya <= g.half && yb >= 1) {                            // bottom-right block rows
-        const int s0 = (g.half + 1) / sw;
-        rects[nr++] = {std::max(ya, 1), std::min(yb, g.half), s0, ns_all - s0};
+    sb = std::min(sb, ns_all);
+    if (ya <= gp.half && yb >= 1) {
+        const int s0 = std::max(sa, s0b);
+        if (s0 < sb) out[nr++] = Rect{std::max(ya, 1), std::min(yb, gp.half), s0, sb, (sa > s0b ? 1 : 0) | (sb < ns_all ? 2 : 0)};
     }
-    if (yb > g.half)                                          // upper block rows
-        rects[nr++] = {std::max(ya, g.half + 1), std::min(yb, g.N - 1), 0, ns_all};
+    if (yb > gp.half && sa < sb)
+        out[nr++] = Rect{std::max(ya, gp.half + 1), std::min(yb, gp.n - 1), sa, sb, (sa > 0 ? 1 : 0) | (sb < ns_all ? 2 : 0)};
+    return nr;
+}
+
+// Append rows [y0, y1] x strips [s0, s1) cut into items of ~ty rows.  Returns the strip-rows added (ty <= 0: only count).
+long long add_panel(WorkList& wl, int y0, int y1, int s0, int s1, int ty, int gc) {
+    const int rows = y1 - y0 + 1, ns = s1 - s0;
+    if (rows <= 0 || ns <= 0) return 0;
+    if (ty <= 0) return (long long)rows * ns;
+    if (wl.np >= kMaxPanels) return 0;
+    Panel& P = wl.p[wl.np++];
+    P.y0 = y0; P.y1 = y1; P.s0 = s0; P.ns = ns; P.gc = gc;
+    P.nchunks = (rows + ty - 1) / ty;
+    P.ty = (rows + P.nchunks - 1) / P.nchunks;            // rebalance
+    P.nchunks = (rows + P.ty - 1) / P.ty;
+    P.item0 = wl.nitems;
+    wl.nitems += P.ns * P.nchunks;
+    return (long long)rows * ns;
+}
+
+// Launch shape for a list of rectangles.  2 048 resident waves (2 workgroups per CU: 8 waves per CU already saturate
+// the memory system, round 1) take the items round-robin, MI355CG_ITEM_ROWS rows each (default 32): short items keep the
+// waves of a round inside one band of rows (see "work items" in cg_kernels.h).  The item height is then nudged so that
+// the item count fills a whole number of rounds -- a last round with a few items would run at a fraction of the chip.
+Plan make_plan(const std::vector<Rect>& rects, int fixed_ty = 0) {
+    Plan pl{};
+    const int target_waves = std::max(kWaves, env_int("MI355CG_WAVES", 2048));
+    const int max_blocks = std::max(1, env_int("MI355CG_BLOCKS", 512));
+    const int waves = std::min(target_waves, max_blocks * kWaves);
+    const int item_rows = std::max(1, env_int("MI355CG_ITEM_ROWS", 32));
     long long strip_rows = 0;
-    for (int i = 0; i < nr; ++i) {
-        const int rows = rects[i].y1 - rects[i].y0 + 1;
-        if (rows <= 0 || wl.np >= kMaxPanels) continue;
-        strip_rows += (long long)rows * rects[i].ns;
-        if (ty <= 0) continue;                                // dry run: only count
-        Panel& P = wl.p[wl.np++];
-        P.y0 = rects[i].y0; P.y1 = rects[i].y1; P.s0 = rects[i].s0; P.ns = rects[i].ns;
-        P.nchunks = (rows + ty - 1) / ty;
-        P.ty = (rows + P.nchunks - 1) / P.nchunks;            // rebalance
-        P.nchunks = (rows + P.ty - 1) / P.ty;
-        P.item0 = wl.nitems;
-        wl.nitems += P.ns * P.nchunks;
+    WorkList dry{};
+    for (auto& r : rects) strip_rows += add_panel(dry, r.y0, r.y1, r.s0, r.s1, 0, 0);
+    if (strip_rows == 0) return pl;
+    int ty = fixed_ty;
+    if (ty <= 0) {
+        const long long rounds = std::max<long long>(1, (strip_rows + (long long)waves * item_rows / 2) / ((long long)waves * item_rows));
+        ty = (int)std::max<long long>(std::min<long long>(8, item_rows), (strip_rows + rounds * waves - 1) / (rounds * waves));
+        for (int tries = 0; tries < 64; ++tries) {
+            pl.wl = WorkList{};
+            for (auto& r : rects) add_panel(pl.wl, r.y0, r.y1, r.s0, r.s1, ty, r.gc);
+            if (pl.wl.nitems <= rounds * waves || (tries == 0 && pl.wl.nitems <= waves)) break;
+            ++ty;
+        }
+    } else {
+        for (auto& r : rects) add_panel(pl.wl, r.y0, r.y1, r.s0, r.s1, ty, r.gc);
     }
-    return strip_rows;
+    pl.ty = ty;
+    pl.grid = std::max(1, std::min(max_blocks, (pl.wl.nitems + kWaves - 1) / kWaves));
+    return pl;
 }
 
-void build_worklist(mi355cg_ctx* c, int vec) {
+void build_plans(mi355cg_ctx* c) {
     const Geom& g = c->g;
-    WorkList dry{}; 
-    const long long strip_rows = add_panels(g, vec, g.y_lo, g.y_hi, 0, dry);
-    // 2 048 waves = 2 workgroups per CU: measured best at every size from N = 2048 to 16384 (+4-5 % over 4 096 waves of
-    // half the height at N = 4096 / 8192 / 16384: less halo re-read, and 8 waves per CU already saturate the memory system)
-    const int target_waves = std::max(1, env_int("MI355CG_STENCIL_WAVES", 2048));
-    // Items are dealt to the resident waves round-robin, so the launch takes `rounds` full items per wave -- and one more
-    // if the item count spills over rounds * waves by even a single item.  By default there is ONE round: one item per
-    // wave, as tall as it takes (ty = 50 at N = 4096, 196 at N = 8192); MI355CG_MAX_ROWS caps the height and adds rounds.
-    // The item height is the smallest one whose item count fits into the rounds.
-    // the kernels address an item's rows with 32-bit byte offsets from its first row: (ty + 2) * pitch * 8 must stay below 2^31
-    const int addr_rows = (int)std::min<long long>(1 << 20, 0x7fffffffLL / ((long long)g.Pu * 8) - 70);   // (the fit loop below may add up to 64 rows)
-    const int max_rows = std::max(1, std::min(env_int("MI355CG_MAX_ROWS", 1 << 20), addr_rows));
-    const long long rounds = std::max<long long>(1, (strip_rows + (long long)target_waves * max_rows - 1) / ((long long)target_waves * max_rows));
-    int ty = (int)((strip_rows + rounds * target_waves - 1) / (rounds * target_waves));
-    ty = std::max(env_int("MI355CG_MIN_ROWS", 8), ty);
-    if (env_int("MI355CG_ROWS", 0) > 0) ty = env_int("MI355CG_ROWS", 0);
-    for (int tries = 0; tries < 64; ++tries) {
-        c->wl = WorkList{};
-        add_panels(g, vec, g.y_lo, g.y_hi, ty, c->wl);
-        if (env_int("MI355CG_ROWS", 0) > 0 || c->wl.nitems <= rounds * target_waves || env_int("MI355CG_FIT_ROUNDS", 1) == 0) break;
-        ++ty;
+    const GridParams& gp = c->gp;
+    Rect rr[2];
+    const int nr = region_rects(gp, 2, g.y_lo, g.y_hi, c->s_lo, c->s_hi, rr);
+    std::vector<Rect> whole(rr, rr + nr);
+    c->whole = make_plan(whole);
+    c->has_gc = false;
+    for (auto& r : whole) if (r.gc) c->has_gc = true;
+    // split for halo / compute overlap: `edge` = everything that reads ghost data of r (first and last owned row, the
+    // strips beside a ghost column), `interior` = the rest
+    std::vector<Rect> inner, rows, cols;
+    for (auto& r : whole) {
+        const int yi0 = std::max(r.y0, g.y_lo + 1), yi1 = std::min(r.y1, g.y_hi - 1);
+        const int si0 = r.s0 + ((r.gc & 1) ? 1 : 0), si1 = r.s1 - ((r.gc & 2) ? 1 : 0);
+        if (r.y0 <= g.y_lo && g.y_lo <= r.y1) rows.push_back(Rect{g.y_lo, g.y_lo, r.s0, r.s1, r.gc});
+        if (g.y_hi > g.y_lo && r.y0 <= g.y_hi && g.y_hi <= r.y1) rows.push_back(Rect{g.y_hi, g.y_hi, r.s0, r.s1, r.gc});
+        if (yi0 > yi1) continue;
+        if (si0 < si1) inner.push_back(Rect{yi0, yi1, si0, si1, 0});
+        if (si0 >= si1) { cols.push_back(Rect{yi0, yi1, r.s0, r.s1, r.gc}); continue; }     // too narrow to have an interior
+        if (r.gc & 1) cols.push_back(Rect{yi0, yi1, r.s0, r.s0 + 1, 1});
+        if (r.gc & 2) cols.push_back(Rect{yi0, yi1, r.s1 - 1, r.s1, 2});
     }
-    c->rows_per_item = ty;
-    const int max_blocks = std::max(1, env_int("MI355CG_STENCIL_BLOCKS", 512));
-    c->grid_stencil = std::max(1, std::min(max_blocks, (c->wl.nitems + kWaves - 1) / kWaves));
-    // slab split for halo/compute overlap: edge rows (need the neighbours' ghost rows) and interior rows
-    c->wl_edge = WorkList{}; c->wl_int = WorkList{};
-    add_panels(g, vec, g.y_lo, g.y_lo, 1, c->wl_edge);
-    if (g.y_hi > g.y_lo) add_panels(g, vec, g.y_hi, g.y_hi, 1, c->wl_edge);
-    if (g.y_hi - g.y_lo >= 2) add_panels(g, vec, g.y_lo + 1, g.y_hi - 1, ty, c->wl_int);
-    c->grid_edge = std::max(1, (c->wl_edge.nitems + kWaves - 1) / kWaves);
-    c->grid_int = std::max(1, std::min(max_blocks, (c->wl_int.nitems + kWaves - 1) / kWaves));
-    const long long nvec = g.own_len / vec;
-    const int max_upd = std::max(1, env_int("MI355CG_UPDATE_BLOCKS", 512));
-    c->update_mode = env_int("MI355CG_UPDATE_MODE", 0);          // 0: flat sweep, 1: 2-D chunks shared with the stencil
-    c->stencil_desc = env_int("MI355CG_STENCIL_DESC", 0);        // march direction of the stencil chunks
-    c->update_desc = env_int("MI355CG_UPDATE_DESC", 1);          // the flat update sweeps from the end: it starts on what the stencil touched last
-    c->update_unroll = env_int("MI355CG_UPDATE_UNROLL", 4);
-    if (c->update_mode == 1) c->grid_update = std::max(1, std::min(max_upd, (c->wl.nitems + kWaves - 1) / kWaves));
-    else c->grid_update = (int)std::max<long long>(1, std::min<long long>(max_upd, (nvec + kBlock - 1) / kBlock));
-    c->depth = env_int("MI355CG_DEPTH", 4);
-    c->nt_mask = env_int("MI355CG_NT", 0);
-    c->xfuse = env_int("MI355CG_XFUSE", 1);
-    c->xdepth = env_int("MI355CG_XDEPTH", 2);
+    c->interior = make_plan(inner);
+    // edge rows are single-row items; edge strips are cut like the interior
+    Plan e_rows = make_plan(rows, 1), e_cols = make_plan(cols, c->interior.ty > 0 ? c->interior.ty : 0);
+    c->edge = e_rows;
+    for (int k = 0; k < e_cols.wl.np && c->edge.wl.np < kMaxPanels; ++k) {
+        Panel P = e_cols.wl.p[k];
+        P.item0 = c->edge.wl.nitems;
+        c->edge.wl.p[c->edge.wl.np++] = P;
+        c->edge.wl.nitems += P.ns * P.nchunks;
+    }
+    c->edge.grid = std::max(1, std::min(std::max(1, env_int("MI355CG_BLOCKS", 512)), (c->edge.wl.nitems + kWaves - 1) / kWaves));
+    if (c->edge.wl.nitems == 0) c->edge.grid = 0;
+    if (c->dtype == MI355CG_F32_MIXED) {                  // the fp32 kernels use 256-column strips (float4 per lane) on the same pitches
+        Rect r4[2];
+        const int n4 = region_rects(gp, 4, g.y_lo, g.y_hi, 0, strips_total(gp, 4), r4);
+        c->whole32 = make_plan(std::vector<Rect>(r4, r4 + n4));
+    }
+    c->depth = env_int("MI355CG_DEPTH", 2) == 3 ? 3 : 2;
     c->use_graph = env_int("MI355CG_GRAPH", -1);
-    c->recompute = env_int("MI355CG_RECOMPUTE", 1);
-    c->udepth = env_int("MI355CG_UDEPTH", 2);
-    c->udepth_full = env_int("MI355CG_UDEPTH_FULL", 2);
-    c->msg_depth = env_int("MI355CG_MSG_DEPTH", 2);
-    c->x2step = env_int("MI355CG_X2STEP", 1);        // REL_2NORM: x is updated every second iteration, two steps at once (7.5 words)
-    c->sdepth = env_int("MI355CG_SDEPTH", 2);
-    c->nB_own = c->grid_update;
+    c->nB_own = c->whole.grid;
 }
 
-PackGeom pack_geom(const mi355cg_ctx* c) {
-    PackGeom pg; pg.g = c->g; pg.pk_begin = c->pk_begin; pg.pk_len = c->pk_len; pg.bottom_size = c->gp.bottom_size;
-    return pg;
-}
 int flat_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>(2048, (n + kBlock - 1) / kBlock)); }
 
 // ---- launchers -------------------------------------------------------------------------------------
 // Where a consumer kernel finds the partials it reduces in its prologue: the producer kernel's own
 // field-major array (estride 1) or partials all-gathered across ranks, rank-major (estride = #fields).
 struct PartSrc { const double* ptr; int n, fstride, estride; };
-// Which rows a stencil launch covers and where it runs.
-struct StencilWhere { hipStream_t stream; const WorkList* wl; int grid; int slotA; };
+// Which items a launch covers, where it runs, and the first partial slot it writes.
+struct Where { hipStream_t stream; const Plan* plan; int slot; };
 
-template <typename T, int VEC, bool FUSED, bool MSG, bool DESC>
-void launch_stencil_dir(const mi355cg_ctx* c, const StencilArgs<T>& a, const StencilWhere& w) {
-    dim3 grid(w.grid), block(kBlock);
-    switch (c->depth) {
-        case 2: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 2, DESC>), grid, block, 0, w.stream, a); break;
-        case 8: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 8, DESC>), grid, block, 0, w.stream, a); break;
-        default: hipLaunchKernelGGL((k_stencil<T, VEC, FUSED, MSG, 4, DESC>), grid, block, 0, w.stream, a); break;
-    }
-}
-template <typename T, int VEC, bool FUSED, bool MSG>
-void launch_stencil_depth(const mi355cg_ctx* c, const StencilArgs<T>& a, const StencilWhere& w) {
-    if (c->stencil_desc) launch_stencil_dir<T, VEC, FUSED, MSG, true>(c, a, w);
-    else launch_stencil_dir<T, VEC, FUSED, MSG, false>(c, a, w);
-}
-// fused stencil that also applies the previous iteration's x update (REL_2NORM fast path)
-template <typename T, int VEC, bool NOAP>
-void launch_stencil_xupd(const mi355cg_ctx* c, const StencilArgs<T>& a, const StencilWhere& w) {
-    dim3 grid(w.grid), block(kBlock);
-    // 2 rows in flight: with the extra x stream 4 rows need 138 VGPRs (3 waves/SIMD, the 4096-wave grid no
-    // longer fits at once); 2 rows need 104 (4 waves/SIMD) and measured 5 % faster (profiles/r01_tune_notes.md)
-    if (c->xdepth == 4) hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 4, false, true, NOAP>), grid, block, 0, w.stream, a);
-    else hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 2, false, true, NOAP>), grid, block, 0, w.stream, a);
-}
+Where whole_part(const mi355cg_ctx* c) { return Where{c->stream, &c->whole, 0}; }
+PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, c->nB_own, c->strideB, 1}; }
+PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, c->whole.grid, c->strideA, 1}; }
 
-template <typename T, int VEC>
-StencilArgs<T> stencil_args_common(const mi355cg_ctx* c, const StencilWhere& w) {
-    StencilArgs<T> a{};
-    a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC);
-    a.wl = *w.wl;
-    return a;
-}
-StencilWhere whole_slab(const mi355cg_ctx* c) { return StencilWhere{c->stream, &c->wl, c->grid_stencil, 0}; }
+template <typename T, int VEC> Geom kernel_geom(const mi355cg_ctx* c) { Geom g = c->g; g.xlim = (int)round_up(c->g.N + 1, VEC); return g; }
 
 // y = A_h v (plain operator apply on storage-layout vectors)
 template <typename T, int VEC>
-void launch_apply(const mi355cg_ctx* c, const T* v, T* out) {
-    const StencilWhere w = whole_slab(c);
-    StencilArgs<T> a = stencil_args_common<T, VEC>(c, w);
+void launch_apply(const mi355cg_ctx* c, const T* v, T* out, const Where& w) {
+    if (w.plan->wl.nitems == 0) return;
+    StencilArgs<T> a{};
+    a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
     a.pin = v; a.ap = out; a.partA = nullptr;
-    launch_stencil_depth<T, VEC, false, false>(c, a, w);
+    hipLaunchKernelGGL((k_stencil<T, VEC, false, false, 2, false, false>), dim3(w.plan->grid), dim3(kBlock), 0, w.stream, a);
 }
 
-struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool xfuse = false; bool recomp = false; bool x2 = false; };
+struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool x2 = false; };
 
-// Phase A'.  Does NOT flip c->cur (a slab's interior and edge launches share one direction pair).
+// Phase A'.  Does NOT flip c->cur (a part's interior and edge launches share one direction pair).
 template <typename T, int VEC>
-void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], T* ap,
-                              const StencilWhere& w, const PartSrc& pb, T* x = nullptr) {
-    StencilArgs<T> a = stencil_args_common<T, VEC>(c, w);
-    a.r = r; a.pin = p[c->cur]; a.pout = p[c->cur ^ 1]; a.ap = ap;
+void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], const Where& w, const PartSrc& pb) {
+    if (w.plan->wl.nitems == 0) return;
+    StencilArgs<T> a{};
+    a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
+    a.r = r; a.pin = p[c->cur]; a.pout = p[c->cur ^ 1]; a.ap = nullptr;
     a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
-    a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slotA;
+    a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slot;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     a.store_ghosts = c->is_slab ? 1 : 0;
-    if (cfg.recomp && cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) {        // A p is not stored: the update launch recomputes it
-        dim3 grid(w.grid), block(kBlock);
-        // 2 rows in flight: 4 rows cost a fourth wave per SIMD and measured 9 % slower (profiles/r01_tune_notes.md)
-        if (c->msg_depth == 2) hipLaunchKernelGGL((k_stencil<T, VEC, true, true, 2, false, false, true>), grid, block, 0, w.stream, a);
-        else hipLaunchKernelGGL((k_stencil<T, VEC, true, true, 4, false, false, true>), grid, block, 0, w.stream, a);
+    const dim3 grid(w.plan->grid), block(kBlock);
+    const bool msg = cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM, gc = c->has_gc, d3 = c->depth == 3;
+#define MI355CG_ST(MSG, D, GC) hipLaunchKernelGGL((k_stencil<T, VEC, true, MSG, D, true, GC>), grid, block, 0, w.stream, a)
+    if constexpr (VEC == 2) {
+        if (msg) { if (gc) { if (d3) MI355CG_ST(true, 3, true); else MI355CG_ST(true, 2, true); } else { if (d3) MI355CG_ST(true, 3, false); else MI355CG_ST(true, 2, false); } }
+        else     { if (gc) { if (d3) MI355CG_ST(false, 3, true); else MI355CG_ST(false, 2, true); } else { if (d3) MI355CG_ST(false, 3, false); else MI355CG_ST(false, 2, false); } }
+    } else {
+        if (d3) MI355CG_ST(false, 3, false); else MI355CG_ST(false, 2, false);       // fp32 inner CG: REL_2NORM, single GPU
     }
-    else if (cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM) launch_stencil_depth<T, VEC, true, true>(c, a, w);
-    else if (cfg.x2) {          // x is handled by the update launch (every second iteration): r, p in, p out
-        dim3 grid(w.grid), block(kBlock);
-        if (c->sdepth == 2) hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 2, false, false, true>), grid, block, 0, w.stream, a);
-        else hipLaunchKernelGGL((k_stencil<T, VEC, true, false, 4, false, false, true>), grid, block, 0, w.stream, a);
-    }
-    else if (cfg.xfuse && cfg.recomp) { a.x = x; launch_stencil_xupd<T, VEC, true>(c, a, w); }
-    else if (cfg.xfuse) { a.x = x; launch_stencil_xupd<T, VEC, false>(c, a, w); }
-    else launch_stencil_depth<T, VEC, true, false>(c, a, w);
+#undef MI355CG_ST
 }
-#ifdef MI355CG_WAVE_TIMING     // diagnostic build: MI355CG_FAKE_NB=1 makes the prologues reduce ONE partial (wrong numbers, right timing of everything else)
-static int fake_nb() { static int v = env_int("MI355CG_FAKE_NB", 0); return v; }
-PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, fake_nb() ? 1 : c->nB_own, c->strideB, 1}; }
-PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, fake_nb() ? 1 : c->grid_stencil, c->strideA, 1}; }
-#else
-PartSrc own_partB(const mi355cg_ctx* c) { return PartSrc{c->partB, c->nB_own, c->strideB, 1}; }
-PartSrc own_partA(const mi355cg_ctx* c) { return PartSrc{c->partA, c->grid_stencil, c->strideA, 1}; }
-#endif
 
+// Phase B on the stencil's work items, marched the other way (it starts on what the stencil launch touched last).
+// c->cur was flipped after this iteration's stencil launch: it is the iteration number's parity.
 template <typename T, int VEC>
-void launch_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, bool init,
-                   hipStream_t stream, const PartSrc& pa, double resume_r0norm = -1.0, const StencilWhere* where = nullptr,
-                   const T* pprev = nullptr) {
-    if (cfg.recomp && !init && resume_r0norm < 0.0) {
-        // recomputing update on the stencil's work items, marched the other way (it starts on what the stencil touched last)
-        const StencilWhere w = where ? *where : StencilWhere{stream, &c->wl, c->grid_stencil, 0};
-        UpdateStArgs<T> a{};
-        a.g = c->g; a.g.xlim = (int)round_up(c->g.N + 1, VEC); a.wl = *w.wl;
-        a.p = p; a.r = r; a.x = x; a.u = u; a.pprev = pprev;
-            a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
-        a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slotA;
-        a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = c->update_desc;
-        dim3 grid(w.grid), block(kBlock);
-        const bool heavy = cfg.x2 ? (c->cur == 0 && pprev) : !cfg.xfuse;     // this launch also streams x (and p_prev or u)
-        const int ud = heavy ? c->udepth_full : c->udepth;                    // rows in flight
-#define MI355CG_UST(XM, HASU) do { \
-        if (c->update_desc) { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, true>), grid, block, 0, w.stream, a); \
-                              else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 4, true>), grid, block, 0, w.stream, a); } \
-        else                { if (ud == 2) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, false>), grid, block, 0, w.stream, a); \
-                              else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 4, false>), grid, block, 0, w.stream, a); } } while (0)
-        // c->cur was flipped after this iteration's stencil launch: it is the iteration number's parity
-        if (cfg.x2) { if (c->cur == 0 && pprev) MI355CG_UST(2, false); else MI355CG_UST(0, false); }
-        else if (cfg.xfuse) MI355CG_UST(0, false);
-        else if (cfg.has_u) MI355CG_UST(1, true);
-        else MI355CG_UST(1, false);
+void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* const p[2], const T* u, const Where& w, const PartSrc& pa) {
+    if (w.plan->wl.nitems == 0) return;
+    UpdateStArgs<T> a{};
+    a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
+    a.p = p[c->cur]; a.pprev = p[c->cur ^ 1]; a.r = r; a.x = x; a.u = u;
+    a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
+    a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slot;
+    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
+    const dim3 grid(w.plan->grid), block(kBlock);
+    const bool d3 = c->depth == 3;
+#define MI355CG_UST(XM, HASU) do { if (d3) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 3, true>), grid, block, 0, w.stream, a); \
+                                   else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, true>), grid, block, 0, w.stream, a); } while (0)
+    if (cfg.x2) { if (c->cur == 0) MI355CG_UST(2, false); else MI355CG_UST(0, false); }      // even iterations carry both x steps
+    else if constexpr (VEC == 2) { if (cfg.has_u) MI355CG_UST(1, true); else MI355CG_UST(1, false); }
 #undef MI355CG_UST
-        return;
-    }
+}
+
+// Flat pass over the owned rows: state initialisation (x = 0, r = b: norms of r0) or the resume step of the mixed path.
+template <typename T, int VEC>
+void launch_update_flat(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T* p, const T* ap, const T* u, hipStream_t stream,
+                        int grid, double resume_r0norm = -1.0) {
     UpdateArgs<T> a{};
     a.begin = c->g.own_begin / VEC; a.nvec = c->g.own_len / VEC;
     a.x = x; a.r = r; a.p = p; a.ap = ap; a.u = u;
-    a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
+    a.partA = c->partA; a.nA = 0; a.strideA = c->strideA; a.esA = 1;
     a.partB = c->partB; a.strideB = c->strideB;
-    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = c->update_desc; a.nt = init ? 0 : c->nt_mask;
-    a.light = (!init && cfg.xfuse) ? 1 : 0;
-    if (resume_r0norm >= 0.0) { a.init = 2; a.r0norm_resume = resume_r0norm; a.s_in = c->sB; a.light = 0; }   // measure + re-arm, see k_update
-    dim3 grid(c->update_mode == 1 ? c->grid_update : c->nB_own), block(kBlock);
-    if (c->update_mode == 1 && !a.light && a.init != 2) {
-        Update2DArgs<T> aa{};
-        aa.g = c->g; aa.g.xlim = (int)round_up(c->g.N + 1, VEC); aa.wl = c->wl; aa.u = a;
-#define MI355CG_U2D(HASU, UNR, DESC) hipLaunchKernelGGL((k_update2d<T, VEC, HASU, UNR, DESC>), grid, block, 0, stream, aa)
-        const bool d = c->update_desc != 0;
-        if (c->update_unroll == 2) {
-            if (cfg.has_u) { if (d) MI355CG_U2D(true, 2, true); else MI355CG_U2D(true, 2, false); }
-            else           { if (d) MI355CG_U2D(false, 2, true); else MI355CG_U2D(false, 2, false); }
-        } else {
-            if (cfg.has_u) { if (d) MI355CG_U2D(true, 4, true); else MI355CG_U2D(true, 4, false); }
-            else           { if (d) MI355CG_U2D(false, 4, true); else MI355CG_U2D(false, 4, false); }
-        }
-#undef MI355CG_U2D
-        return;
-    }
-    if (cfg.has_u) hipLaunchKernelGGL((k_update<T, VEC, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((k_update<T, VEC, false>), grid, block, 0, stream, a);
+    a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = 1;
+    if (resume_r0norm >= 0.0) { a.init = 2; a.r0norm_resume = resume_r0norm; a.s_in = c->sB; }   // measure + re-arm, see k_update
+    if (cfg.has_u) hipLaunchKernelGGL((k_update<T, VEC, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL((k_update<T, VEC, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+}
+
+template <typename T, int VEC>
+void launch_flush_x(const mi355cg_ctx* c, const Plan& plan, T* x, const T* p, T alpha, hipStream_t stream) {
+    if (plan.wl.nitems == 0) return;
+    hipLaunchKernelGGL((k_flush_x<T, VEC>), dim3(std::max(1, std::min(1024, (plan.wl.nitems + kWaves - 1) / kWaves))), dim3(kBlock), 0, stream,
+                       kernel_geom<T, VEC>(c), plan.wl, x, p, alpha);
 }
 
 void launch_check(mi355cg_ctx* c, const IterCfg& cfg, hipStream_t stream, const PartSrc& pb) {
@@ -380,6 +369,8 @@ void launch_check(mi355cg_ctx* c, const IterCfg& cfg, hipStream_t stream, const 
     hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, stream, a);
 }
 
+// The launch shapes of an iteration: REL_2NORM without diagnostics = two-step x update (7.5 words per unknown);
+// MSG, and REL_2NORM with the reference's per-iteration diagnostics = x and its norms every iteration (8 words, + u when read).
 IterCfg make_cfg(const mi355cg_params* prm) {
     IterCfg cfg{};
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
@@ -391,6 +382,7 @@ IterCfg make_cfg(const mi355cg_params* prm) {
     cfg.has_u = (msg && prm->use_true_solution) || diag;
     cfg.rp.use_u = cfg.has_u ? 1 : 0;
     cfg.want_diag = diag ? 1 : 0;
+    cfg.x2 = !msg && !diag;
     return cfg;
 }
 
@@ -402,8 +394,9 @@ int upload_packed(mi355cg_ctx* c, const double* host_packed, T* storage) {
         return MI355CG_OK;
     }
     if (c->is_slab) HIPCK(hipDeviceSynchronize());
+    if (c->pk_len == 0) return MI355CG_OK;
     HIPCK(hipMemcpyAsync(c->packed, host_packed, sizeof(double) * c->pk_len, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL((k_unpack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), c->packed, storage);
+    hipLaunchKernelGGL((k_unpack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, c->pg, c->packed, storage);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(c->stream));
     return MI355CG_OK;
@@ -415,8 +408,9 @@ int download_packed(mi355cg_ctx* c, const T* storage, double* host_packed) {
         HIPCK(hipStreamSynchronize(c->stream));
         return MI355CG_OK;
     }
-    if (c->is_slab) HIPCK(hipDeviceSynchronize());      // slab phases run on the caller's streams
-    hipLaunchKernelGGL((k_pack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), storage, c->packed);
+    if (c->is_slab) HIPCK(hipDeviceSynchronize());      // part phases run on the caller's / the team's streams
+    if (c->pk_len == 0) return MI355CG_OK;
+    hipLaunchKernelGGL((k_pack<T>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, c->pg, storage, c->packed);
     HIPCK(hipGetLastError());
     HIPCK(hipMemcpyAsync(host_packed, c->packed, sizeof(double) * c->pk_len, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
@@ -435,17 +429,23 @@ int ensure_u_on_device(mi355cg_ctx* c) {
     c->have_u_dev = true;
     return MI355CG_OK;
 }
+// Work space of mi355cg_apply / mi355cg_get_true_residual.  The reference's apply is const and may be called from an
+// iteration callback in the middle of a solve, so it must never borrow a solver vector.
+int ensure_scratch(mi355cg_ctx* c) {
+    for (auto& s : c->scratch) if (!s) { if (int rc = alloc_vec(&s, c->storage_len)) return rc; }
+    HIPCK(hipDeviceSynchronize());      // the zero-fill ran on the NULL stream
+    return MI355CG_OK;
+}
 
 void clear_graphs(mi355cg_ctx* c) {
     for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
     c->graphs.clear();
 }
 
-void prof_begin(mi355cg_ctx* c, int k, hipEvent_t* e0) {
+void prof_begin(mi355cg_ctx* c, hipEvent_t* e0) {
     if (!c->profiling) return;
     *e0 = c->events.get();
     if (*e0) hipEventRecord(*e0, c->stream);
-    (void)k;
 }
 void prof_end(mi355cg_ctx* c, int k, hipEvent_t e0) {
     if (!c->profiling || !e0) return;
@@ -503,7 +503,7 @@ int solve_csr(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, voi
         a.x = c->x; a.r = c->r; a.p = c->p[0]; a.ap = c->ap; a.u = c->u;
         a.partA = pA.ptr; a.nA = pA.n; a.strideA = pA.fstride; a.esA = 1;
         a.partB = c->partB; a.strideB = c->strideB;
-        a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0; a.reverse = 0; a.nt = 0; a.light = 0;
+        a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.init = init ? 1 : 0;
         if (with_u) hipLaunchKernelGGL((k_update<double, 1, true>), dim3(c->grid_update), dim3(kBlock), 0, c->stream, a);
         else hipLaunchKernelGGL((k_update<double, 1, false>), dim3(c->grid_update), dim3(kBlock), 0, c->stream, a);
     };
@@ -522,11 +522,13 @@ int solve_csr(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, voi
     const int every = prm->callback_every;
     const int sync_every = std::min(prm->sync_every > 0 ? prm->sync_every : (msg ? 100 : 200), kHist);
     int it_done = 0;
+    bool first_chunk = (cb != nullptr || stop_flag != nullptr);
     bool interrupted = false;
     while (!c->summary_h->done) {
         if (stop_flag && *stop_flag) { interrupted = true; break; }
         int m = std::min(sync_every, prm->max_iterations - it_done);
         if (msg && every > 0) m = std::min(m, every - it_done % every);
+        if (first_chunk) { m = 1; first_chunk = false; }     // deliver the it == 1 callback / honour a stop request before queueing more
         if (m <= 0) m = 1;
         for (int k = 0; k < m; ++k) {
             XpayArgs xa{};
@@ -568,19 +570,12 @@ int solve_csr(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, voi
 
 }  // namespace
 
+
 // ---- F32_MIXED: fp32 inner CG inside fp64 iterative refinement ------------------------------------
 // No reference twin (the reference is fp64 only): the pin is the fp64 TRUE residual of the returned x,
 // computed with the bit-exact fp64 operator.  Outer step: d = CG_fp32(A, (float) r) ; x += d ;
 // r = b - A x in fp64.  Only the relative 2-norm rule is offered.
 namespace {
-
-struct PlanSwap {       // run the launch helpers on the fp32 launch geometry for the lifetime of the guard
-    mi355cg_ctx* c; WorkList wl; int gs, gu;
-    explicit PlanSwap(mi355cg_ctx* c_) : c(c_), wl(c_->wl), gs(c_->grid_stencil), gu(c_->grid_update) {
-        c->wl = c->plan32.wl; c->grid_stencil = c->plan32.grid_stencil; c->grid_update = c->plan32.grid_update;
-    }
-    ~PlanSwap() { c->wl = wl; c->grid_stencil = gs; c->grid_update = gu; }
-};
 
 int poll_summary(mi355cg_ctx* c, const IterCfg& cfg) {
     launch_check(c, cfg, c->stream, own_partB(c));
@@ -594,8 +589,9 @@ int poll_summary(mi355cg_ctx* c, const IterCfg& cfg) {
 // residual; keep the direction and the CG scalars, restart only the correction vector xf and the reference norm.
 int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volatile int* stop_flag, int* its, bool* interrupted,
                  double resume_r0norm = -1.0) {
-    PlanSwap guard(c);
-    c->nB_own = cfg.recomp ? c->grid_stencil : c->grid_update;
+    const Where w{c->stream, &c->whole32, 0};
+    const PartSrc pA{c->partA, c->whole32.grid, c->strideA, 1};
+    c->nB_own = c->whole32.grid;
     const size_t bytes = sizeof(float) * c->storage_len;
     HIPCK(hipMemsetAsync(c->xf, 0, bytes, c->stream));
     int done_its = 0;
@@ -604,10 +600,10 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
         HIPCK(hipMemsetAsync(c->pf[1], 0, bytes, c->stream));
         HIPCK(hipMemsetAsync(c->apf, 0, bytes, c->stream));
         c->cur = 0;
-        launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[0], c->apf, (const float*)nullptr, true, c->stream, own_partA(c));
+        launch_update_flat<float, 4>(c, cfg, c->xf, c->rf, c->pf[0], c->apf, (const float*)nullptr, c->stream, c->whole32.grid);
     } else {
         done_its = c->summary_h->it;
-        launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[c->cur], c->apf, (const float*)nullptr, false, c->stream, own_partA(c), resume_r0norm);
+        launch_update_flat<float, 4>(c, cfg, c->xf, c->rf, c->pf[c->cur], c->apf, (const float*)nullptr, c->stream, c->whole32.grid, resume_r0norm);
     }
     HIPCK(hipGetLastError());
     if (int rc = poll_summary(c, cfg)) return rc;
@@ -616,12 +612,12 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
         const int m = std::max(1, std::min(sync_every, cfg.rp.max_iterations - done_its));
         for (int k = 0; k < m; ++k) {
             hipEvent_t e0 = nullptr;
-            prof_begin(c, 0, &e0);
-            launch_iteration_stencil<float, 4>(c, cfg, c->rf, c->pf, c->apf, whole_slab(c), own_partB(c), c->xf);
+            prof_begin(c, &e0);
+            launch_iteration_stencil<float, 4>(c, cfg, c->rf, c->pf, w, own_partB(c));
             c->cur ^= 1;
             prof_end(c, 0, e0);
-            prof_begin(c, 1, &e0);
-            launch_update<float, 4>(c, cfg, c->xf, c->rf, c->pf[c->cur], c->apf, (const float*)nullptr, false, c->stream, own_partA(c), -1.0, nullptr, c->pf[c->cur ^ 1]);
+            prof_begin(c, &e0);
+            launch_iteration_update<float, 4>(c, cfg, c->xf, c->rf, c->pf, (const float*)nullptr, w, pA);
             prof_end(c, 1, e0);
         }
         HIPCK(hipGetLastError());
@@ -630,9 +626,8 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
     }
     *its = c->summary_h->it;
     c->cur = *its & 1;
-    if (cfg.xfuse && *its > 0 && (!cfg.x2 || (*its & 1))) {        // the last inner iteration's x += alpha*p is still pending (two-step scheme: only after an odd count)
-        hipLaunchKernelGGL((k_flush_x<float>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream,
-                           c->g.own_begin, c->g.own_len, c->xf, c->pf[c->cur], (float)c->summary_h->alpha);
+    if (*its > 0 && (*its & 1)) {        // two-step scheme: after an odd count the last x += alpha*p is still pending
+        launch_flush_x<float, 4>(c, c->whole32, c->xf, c->pf[c->cur], (float)c->summary_h->alpha, c->stream);
         HIPCK(hipGetLastError());
     }
     return MI355CG_OK;
@@ -673,14 +668,11 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
     while (!converged && total < prm->max_iterations && !interrupted) {
         mi355cg_params ip = *prm;
         ip.eps_rel = inner_eps; ip.diagnostics = 0;
-        // residual replacement (default): the iteration counter runs on across outer steps, so the cap is the global one;
-        // restarted refinement (MI355CG_MIXED_RESTART=1): every inner solve starts from scratch with the remaining budget
+        // restarted refinement: every inner solve starts from scratch with the remaining budget;
+        // residual replacement: the iteration counter runs on across outer steps, so the cap is the global one
         ip.max_iterations = restart ? prm->max_iterations - total : prm->max_iterations;
         if (!restart && stage_cap > 0) ip.max_iterations = std::min(ip.max_iterations, total + stage_cap);
-        IterCfg cfg = make_cfg(&ip);
-        cfg.xfuse = c->xfuse && c->update_mode == 0;
-        cfg.recomp = c->recompute && cfg.xfuse;
-        cfg.x2 = cfg.recomp && c->x2step;
+        const IterCfg cfg = make_cfg(&ip);
         int its = 0;
         const double resume = (!restart && outer > 0) ? rnorm : -1.0;
         if (int rc = inner_cg_f32(c, cfg, sync_every, stop_flag, &its, &interrupted, resume)) return rc;
@@ -688,7 +680,7 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
         total = restart ? total + its : its; ++outer;
         if (!restart && stage_cap == 0) stage_cap = std::max(2000, 3 * its_this);
         hipLaunchKernelGGL(k_accumulate_f32, dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->x, c->xf);
-        launch_apply<double, 2>(c, c->x, c->ap);
+        launch_apply<double, 2>(c, c->x, c->ap, whole_part(c));
         const double prev = rnorm;
         if (int rc = residual_pass(&rnorm)) return rc;
         if (cb) cb(user, total, 0.0, rnorm, 0.0);
@@ -699,7 +691,7 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
     // leave the fp64 residual of the returned x in c->r for mi355cg_get_recursive_residual
     hipLaunchKernelGGL((k_sub<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->ap, c->r);
     HIPCK(hipStreamSynchronize(c->stream));
-    c->solved = true; c->cur = 0;
+    c->solved = true; c->cur = 0; c->nB_own = c->whole.grid;
     prof_collect(c);
     mi355cg_results res{};
     res.iterations = total; res.converged = converged ? 1 : 0;
@@ -718,10 +710,10 @@ int solve_mixed(mi355cg_ctx* c, const mi355cg_params* prm, mi355cg_iter_cb cb, v
 extern "C" {
 
 const char* mi355cg_last_error(void) { return g_err.c_str(); }
-const char* mi355cg_version(void) { return "mi355cg 0.1 (gfx950)"; }
+const char* mi355cg_version(void) { return "mi355cg 0.2 (gfx950)"; }
 
 static int create_impl(int n, int m, double a, double b, double c_, double d, int dtype, int device,
-                       int y_lo, int y_hi, bool slab, mi355cg_handle* out) {
+                       int y_lo, int y_hi, int s_lo, int s_hi, bool part, mi355cg_handle* out) {
     if (!out) return fail(MI355CG_ERR_INVALID, "out is null");
     *out = nullptr;
     if (dtype != MI355CG_F64 && dtype != MI355CG_F32_MIXED) return fail(MI355CG_ERR_INVALID, "unknown dtype %d", dtype);
@@ -734,21 +726,20 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     if (device < 0 || device >= ndev) return fail(MI355CG_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
     HIPCK(hipSetDevice(device));
 
-    if (!slab) { y_lo = 1; y_hi = gp.n - 1; }
+    const int ns_all = strips_total(gp, 2);
+    if (!part) { y_lo = 1; y_hi = gp.n - 1; s_lo = 0; s_hi = ns_all; }
     if (y_lo < 1 || y_hi > gp.n - 1 || y_lo > y_hi)
-        return fail(MI355CG_ERR_INVALID, "slab rows [%d, %d] outside 1..%d", y_lo, y_hi, gp.n - 1);
+        return fail(MI355CG_ERR_INVALID, "part rows [%d, %d] outside 1..%d", y_lo, y_hi, gp.n - 1);
+    if (s_lo < 0 || s_hi > ns_all || s_lo >= s_hi)
+        return fail(MI355CG_ERR_INVALID, "part strips [%d, %d) outside 0..%d", s_lo, s_hi, ns_all);
+    if (dtype == MI355CG_F32_MIXED && part) return fail(MI355CG_ERR_INVALID, "F32_MIXED is single-GPU only");
     mi355cg_ctx* c = new mi355cg_ctx();
-    c->device = device; c->dtype = dtype; c->gp = gp; c->is_slab = slab;
-    const int vec = 2;                      // fp64 layout; the fp32 kernels use VEC=4 on the same pitches
-    build_geom(c, vec, y_lo, y_hi);
-    if (dtype == MI355CG_F32_MIXED) {       // the fp32 kernels use 256-column strips (float4 per lane) on the same pitches
-        build_worklist(c, 4);
-        c->plan32.wl = c->wl; c->plan32.grid_stencil = c->grid_stencil; c->plan32.grid_update = c->grid_update;
-        c->plan32.rows_per_item = c->rows_per_item;
-    }
-    build_worklist(c, vec);
-    c->strideA = std::max({c->grid_stencil, c->grid_int + c->grid_edge, c->plan32.grid_stencil});
-    c->strideB = std::max({c->grid_update, c->plan32.grid_update, c->strideA});   // the recomputing update runs on the stencil's grids
+    c->device = device; c->dtype = dtype; c->gp = gp; c->is_slab = part;
+    c->s_lo = s_lo; c->s_hi = s_hi;
+    build_geom(c, 2, y_lo, y_hi);           // fp64 layout; the fp32 kernels use VEC=4 on the same pitches
+    build_plans(c);
+    c->strideA = std::max({c->whole.grid, c->interior.grid + c->edge.grid, c->whole32.grid, 1});
+    c->strideB = c->strideA;                // the update launches run on the stencil's grids
 
     int rc = MI355CG_OK;
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
@@ -784,20 +775,31 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     // or kernel of the context and wipe it (seen as a right-hand side of zeros -> "converged" at iteration 0).
     HIPCK(hipDeviceSynchronize());
 
-    // problem data on the host in the reference's packed order, then into storage layout on the device
+    // problem data on the host in the part's packed order, then into storage layout on the device
     c->rhs_h.resize(c->pk_len); c->u_h.resize(c->pk_len);
-    grid_fill_rows(gp, c->g.y_lo, c->g.y_hi, c->rhs_h.data(), c->u_h.data(), nullptr, nullptr);
+    grid_fill_box(gp, c->g.y_lo, c->g.y_hi, s_lo * kStripCols, s_hi == ns_all ? gp.n : s_hi * kStripCols, c->rhs_h.data(), c->u_h.data(), nullptr, nullptr);
     if ((rc = upload_packed<double>(c, c->rhs_h.data(), c->b))) return cleanup();
     *out = c;
     return MI355CG_OK;
 }
 
 int mi355cg_create(int n, int m, double a, double b, double c_, double d, int dtype, int device, mi355cg_handle* out) {
-    return create_impl(n, m, a, b, c_, d, dtype, device, 0, 0, false, out);
+    return create_impl(n, m, a, b, c_, d, dtype, device, 0, 0, 0, 0, false, out);
 }
 int mi355cg_create_slab(int n, int m, double a, double b, double c_, double d, int dtype, int device,
                         int y_lo, int y_hi, mi355cg_handle* out) {
-    return create_impl(n, m, a, b, c_, d, dtype, device, y_lo, y_hi, true, out);
+    GridParams gp;
+    if (!grid_params_init(&gp, n, m, a, b, c_, d)) return fail(MI355CG_ERR_INVALID, "grid %dx%d rejected: the L-shaped index map is only consistent for n == m, even, >= 6", n, m);
+    return create_impl(n, m, a, b, c_, d, dtype, device, y_lo, y_hi, 0, strips_total(gp, 2), true, out);
+}
+int mi355cg_create_part(int n, int m, double a, double b, double c_, double d, int dtype, int device,
+                        int y_lo, int y_hi, int x_lo, int x_hi, mi355cg_handle* out) {
+    GridParams gp;
+    if (!grid_params_init(&gp, n, m, a, b, c_, d)) return fail(MI355CG_ERR_INVALID, "grid %dx%d rejected: the L-shaped index map is only consistent for n == m, even, >= 6", n, m);
+    const int ns_all = strips_total(gp, 2);
+    if (x_lo % kStripCols != 0 || (x_hi % kStripCols != 0 && x_hi < gp.n))
+        return fail(MI355CG_ERR_INVALID, "part columns [%d, %d): x-cuts must be multiples of %d", x_lo, x_hi, kStripCols);
+    return create_impl(n, m, a, b, c_, d, dtype, device, y_lo, y_hi, x_lo / kStripCols, x_hi >= gp.n ? ns_all : x_hi / kStripCols, true, out);
 }
 
 int mi355cg_create_csr(long long nrows, const int* row_map, const int* entries, const double* values,
@@ -816,14 +818,12 @@ int mi355cg_create_csr(long long nrows, const int* row_map, const int* entries, 
     mi355cg_ctx* c = new mi355cg_ctx();
     c->device = device; c->dtype = MI355CG_F64; c->is_csr = true;
     c->csr_n = nrows; c->csr_nnz = nnz;
-    c->gp.size = nrows; c->pk_begin = 0; c->pk_len = nrows; c->storage_len = nrows;
+    c->gp.size = nrows; c->pk_begin = 0; c->pk_len = nrows; c->storage_len = nrows; c->pg.pk_len = nrows;
     c->g.own_begin = 0; c->g.own_len = nrows;
     const long long nblk = (nrows + kBlock - 1) / kBlock;
     c->grid_csr = (int)std::max<long long>(1, std::min<long long>(2048, nblk));
     c->grid_update = (int)std::max<long long>(1, std::min<long long>(512, nblk));
-    c->grid_stencil = c->grid_csr;
     c->strideA = c->grid_csr; c->strideB = c->grid_update; c->nB_own = c->grid_update;
-    c->update_mode = 0;
     int rc = MI355CG_OK;
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "hipStreamCreate failed"); return cleanup(); }
@@ -869,7 +869,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->xf, c->rf, c->pf[0], c->pf[1], c->apf, c->bf,
+    void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf, c->pf[0], c->pf[1], c->apf,
                    c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
     for (void* p : dev) if (p) hipFree(p);
     if (c->csr_row_map) hipFree(c->csr_row_map);
@@ -899,7 +899,8 @@ int mi355cg_get_true_solution(mi355cg_handle c, double* out) {
 int mi355cg_get_node_coords(mi355cg_handle c, double* xs, double* ys) {
     if (!c || !xs || !ys) return fail(MI355CG_ERR_INVALID, "null argument");
     if (c->is_csr) return fail(MI355CG_ERR_INVALID, "a CSR handle has no grid coordinates");
-    grid_fill_rows(c->gp, c->g.y_lo, c->g.y_hi, nullptr, nullptr, xs, ys);
+    const int ns_all = strips_total(c->gp, 2);
+    grid_fill_box(c->gp, c->g.y_lo, c->g.y_hi, c->s_lo * kStripCols, c->s_hi == ns_all ? c->gp.n : c->s_hi * kStripCols, nullptr, nullptr, xs, ys);
     return MI355CG_OK;
 }
 int mi355cg_set_rhs(mi355cg_handle c, const double* b) {
@@ -909,9 +910,11 @@ int mi355cg_set_rhs(mi355cg_handle c, const double* b) {
     return upload_packed<double>(c, c->rhs_h.data(), c->b);
 }
 
+// The reference's apply is const (matrix_free_system.hpp:56) and may be called from an iteration callback in the middle
+// of a solve: both entry points work on dedicated scratch vectors, never on a solver vector.
 int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
     if (!c || !x_dev || !y_dev) return fail(MI355CG_ERR_INVALID, "null argument");
-    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one part of a decomposed grid: use the mi355cg_team_* / mi355cg_dist_* entry points");
     HIPCK(hipSetDevice(c->device));
     if (c->is_csr) {
         launch_csr_spmv(c, x_dev, y_dev, nullptr, nullptr, nullptr);
@@ -919,10 +922,10 @@ int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
         HIPCK(hipStreamSynchronize(c->stream));
         return MI355CG_OK;
     }
-    // p[1] <- unpack(x); ap <- A p[1]; y <- pack(ap).  (Scratch use only outside a solve.)
-    hipLaunchKernelGGL((k_unpack<double>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), x_dev, c->p[1]);
-    launch_apply<double, 2>(c, c->p[1], c->ap);
-    hipLaunchKernelGGL((k_pack<double>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, pack_geom(c), c->ap, y_dev);
+    if (int rc = ensure_scratch(c)) return rc;
+    hipLaunchKernelGGL((k_unpack<double>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, c->pg, x_dev, c->scratch[0]);
+    launch_apply<double, 2>(c, c->scratch[0], c->scratch[1], whole_part(c));
+    hipLaunchKernelGGL((k_pack<double>), dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, c->pg, c->scratch[1], y_dev);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(c->stream));
     return MI355CG_OK;
@@ -930,18 +933,14 @@ int mi355cg_apply_device(mi355cg_handle c, const double* x_dev, double* y_dev) {
 
 int mi355cg_apply(mi355cg_handle c, const double* x, double* y) {
     if (!c || !x || !y) return fail(MI355CG_ERR_INVALID, "null argument");
-    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one part of a decomposed grid: use the mi355cg_team_* / mi355cg_dist_* entry points");
     HIPCK(hipSetDevice(c->device));
-    if (c->is_csr) {
-        if (int rc = upload_packed<double>(c, x, c->p[1])) return rc;
-        launch_csr_spmv(c, c->p[1], c->ap, nullptr, nullptr, nullptr);
-        HIPCK(hipGetLastError());
-        return download_packed<double>(c, c->ap, y);
-    }
-    if (int rc = upload_packed<double>(c, x, c->p[1])) return rc;
-    launch_apply<double, 2>(c, c->p[1], c->ap);
+    if (int rc = ensure_scratch(c)) return rc;
+    if (int rc = upload_packed<double>(c, x, c->scratch[0])) return rc;
+    if (c->is_csr) launch_csr_spmv(c, c->scratch[0], c->scratch[1], nullptr, nullptr, nullptr);
+    else launch_apply<double, 2>(c, c->scratch[0], c->scratch[1], whole_part(c));
     HIPCK(hipGetLastError());
-    return download_packed<double>(c, c->ap, y);
+    return download_packed<double>(c, c->scratch[1], y);
 }
 
 void mi355cg_default_params(mi355cg_params* p, int rule) {
@@ -963,23 +962,21 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
                   const volatile int* stop_flag, mi355cg_results* out) {
     if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
     if (prm->rule != MI355CG_RULE_MSG_MAXNORM && prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "unknown rule %d", prm->rule);
-    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one part of a decomposed grid: use the mi355cg_team_* / mi355cg_dist_* entry points");
     HIPCK(hipSetDevice(c->device));
     if (c->is_csr) return solve_csr(c, prm, cb, user, stop_flag, out);
     if (c->dtype == MI355CG_F32_MIXED) return solve_mixed(c, prm, cb, user, stop_flag, out);
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
-    IterCfg cfg = make_cfg(prm);
+    const IterCfg cfg = make_cfg(prm);
     const bool diag = cfg.want_diag != 0;
-    cfg.xfuse = c->xfuse && !msg && !diag && !cfg.has_u && c->update_mode == 0;     // x update rides in the stencil launch
-    cfg.recomp = c->recompute && c->update_mode == 0 && (cfg.xfuse || msg);        // 8-word iteration: A p is never stored
-    cfg.x2 = cfg.recomp && cfg.xfuse && c->x2step;                                 // 7.5 words: x every second iteration, two steps at once
-    c->nB_own = cfg.recomp ? c->grid_stencil : c->grid_update;
+    c->nB_own = c->whole.grid;
     if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
+    if (diag) if (int rc = ensure_scratch(c)) return rc;
 
     const auto t0 = std::chrono::steady_clock::now();
     c->events.reset(); c->ev_pairs[0].clear(); c->ev_pairs[1].clear();
 
-    // x = 0, r = b, z = 0 (the first stencil makes z = r + 0*z = r), A z = 0    msg_solver.cpp:33-39
+    // x = 0, r = b, z = 0 (the first stencil makes z = r + 0*z = r)    msg_solver.cpp:33-39
     const size_t bytes = sizeof(double) * c->storage_len;
     HIPCK(hipMemsetAsync(c->x, 0, bytes, c->stream));
     HIPCK(hipMemsetAsync(c->p[0], 0, bytes, c->stream));
@@ -987,7 +984,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     HIPCK(hipMemsetAsync(c->ap, 0, bytes, c->stream));
     HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
     c->cur = 0;
-    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, /*init=*/true, c->stream, own_partA(c));
+    launch_update_flat<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, c->stream, c->whole.grid);
     HIPCK(hipGetLastError());
 
     auto poll = [&]() -> int {
@@ -1004,13 +1001,16 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     // The reference recomputes ||x - u|| every iteration (msg_solver.cpp:132-139), but the value is only
     // observable through the exact-error criterion, the periodic callbacks and the final report: read u
     // on exactly those iterations (same values), and once more after the loop if the last one skipped it.
-    const int every_cb = prm->callback_every;
-    auto need_u = [&](int it) { return diag || cfg.rp.eps_exact_error > 0 || it == 1 || (every_cb > 0 && it % every_cb == 0); };
-    int sync_every = prm->sync_every > 0 ? prm->sync_every : (diag ? 1 : (msg ? 100 : 200));
-    sync_every = std::min(sync_every, kHist);
     const int every = prm->callback_every;
+    auto need_u = [&](int it) { return diag || cfg.rp.eps_exact_error > 0 || it == 1 || (every > 0 && it % every == 0); };
+    // iterations enqueued between two host polls (the reference polls its stop flag every iteration, msg_solver.cpp:82)
+    int sync_every = prm->sync_every > 0 ? prm->sync_every : (msg ? 100 : 200);
+    sync_every = std::min(sync_every, kHist);
     int it_done = 0;
     bool interrupted = false;
+    // A caller that watches the solve (callback or stop flag) gets the first iteration on its own: the it == 1 callback
+    // is delivered, and a stop requested from it is honoured, before any further work is queued.
+    bool first_chunk = cb != nullptr || stop_flag != nullptr;
     clear_graphs(c);                                             // kernel arguments embed this solve's parameters
     const bool graph_ok = !c->profiling && !diag &&
                           (c->use_graph == 1 || (c->use_graph < 0 && c->g.own_len < (4LL << 20) && prm->max_iterations >= 4 * sync_every));
@@ -1018,25 +1018,26 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         if (stop_flag && *stop_flag) { interrupted = true; break; }            // msg_solver.cpp:82-87
         int m = std::min(sync_every, prm->max_iterations - it_done);
         if (msg && every > 0) m = std::min(m, every - it_done % every);        // land on the callback iterations
+        if (first_chunk) { m = 1; first_chunk = false; }
         if (m <= 0) m = 1;                                                    // lets the kernels record ITERATIONS
         auto enqueue_chunk = [&]() -> int {
             for (int k = 0; k < m; ++k) {
                 hipEvent_t e0 = nullptr;
-                prof_begin(c, 0, &e0);
-                launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, whole_slab(c), own_partB(c), c->x);
+                prof_begin(c, &e0);
+                launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), own_partB(c));
                 c->cur ^= 1;
                 prof_end(c, 0, e0);
-                prof_begin(c, 1, &e0);
+                prof_begin(c, &e0);
                 IterCfg ucfg = cfg;
                 ucfg.has_u = cfg.has_u && need_u(it_done + k + 1);      // skip the u stream when nothing reads the error norm
-                launch_update<double, 2>(c, ucfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, c->stream, own_partA(c), -1.0, nullptr, c->p[c->cur ^ 1]);
+                launch_iteration_update<double, 2>(c, ucfg, c->x, c->r, c->p, c->u, whole_part(c), own_partA(c));
                 prof_end(c, 1, e0);
                 if (diag) {
-                    // MatrixFreeSolver's per-iteration report: second apply for the TRUE residual
-                    // (matrix_free_system.cpp:457-468).  One iteration per poll in this mode.
-                    launch_apply<double, 2>(c, c->x, c->p[c->cur ^ 1]);            // scratch: the inactive direction buffer
-                    hipLaunchKernelGGL((k_resid2<double>), dim3(1024), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->p[c->cur ^ 1], c->partR);
-                    HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * 1024, hipMemcpyDeviceToHost, c->stream));
+                    // MatrixFreeSolver's per-iteration report needs the TRUE residual (matrix_free_system.cpp:457-463): a
+                    // second apply and its norm, all in-stream; the value lands in the history entry of this iteration.
+                    launch_apply<double, 2>(c, c->x, c->scratch[0], whole_part(c));
+                    hipLaunchKernelGGL((k_resid2<double>), dim3(1024), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->scratch[0], c->partR);
+                    hipLaunchKernelGGL(k_resid2_hist, dim3(1), dim3(kBlock), 0, c->stream, c->partR, 1024, c->sB, c->hist);
                 }
             }
             return MI355CG_OK;
@@ -1069,23 +1070,14 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         HIPCK(hipGetLastError());
         if (int rc = poll()) return rc;
         const int it_now = c->summary_h->it;
-        if (diag) {
-            // the stencil that follows would overwrite the scratch anyway: it holds A x, not a direction
-            if (it_now > it_done) {
-                double s = 0; for (int i = 0; i < 1024; ++i) s += c->partR_h[i];
-                const HistEntry& h = c->hist_h[it_now % kHist];
-                if (cb) cb(user, it_now - 1, std::sqrt(h.d2), std::sqrt(s), std::sqrt(h.e2));
-            }
-            // restore the zero-ness contract of the scratch direction buffer's ghost/pad cells: A x is
-            // masked to interior nodes by the kernel, pads stay 0, and the next stencil rewrites it.
-        } else if (msg && cb) {
-            for (int it = it_done + 1; it <= it_now; ++it) {
+        if (cb) for (int it = it_done + 1; it <= it_now; ++it) {
+            const HistEntry& h = c->hist_h[it % kHist];
+            if (diag) {
+                cb(user, it - 1, std::sqrt(h.d2), std::sqrt(h.tr2), std::sqrt(h.e2));     // matrix_free_system.cpp:466-468 (0-based index)
+            } else if (msg) {
                 // callbacks only on iterations that did NOT stop (msg_solver.cpp:172-183 sits after the breaks)
                 const bool stopped_here = c->summary_h->done && c->summary_h->reason != MI355CG_STOP_ITERATIONS && it == it_now;
-                if ((it == 1 || (every > 0 && it % every == 0)) && !stopped_here) {
-                    const HistEntry& h = c->hist_h[it % kHist];
-                    cb(user, it, h.dmax, h.rmax, cfg.has_u ? h.emax : DBL_MAX);
-                }
+                if ((it == 1 || (every > 0 && it % every == 0)) && !stopped_here) cb(user, it, h.dmax, h.rmax, cfg.has_u ? h.emax : DBL_MAX);
             }
         }
         it_done = it_now;
@@ -1094,9 +1086,8 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     // Launches enqueued after the stop decision return in their prologue but still flipped c->cur on the
     // host: the direction of the last REAL iteration is p[it % 2] (the solve starts with cur = 0).
     c->cur = fin.it & 1;
-    if (cfg.xfuse && fin.it > 0 && (!cfg.x2 || (fin.it & 1))) {      // the last iteration's x += alpha*p has not been applied yet (two-step scheme: only after an odd count)
-        hipLaunchKernelGGL((k_flush_x<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream,
-                           c->g.own_begin, c->g.own_len, c->x, c->p[c->cur], fin.alpha);
+    if (cfg.x2 && fin.it > 0 && (fin.it & 1)) {      // two-step scheme: after an odd count the last x += alpha*p is still pending
+        launch_flush_x<double, 2>(c, c->whole, c->x, c->p[c->cur], fin.alpha, c->stream);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(c->stream));
     }
@@ -1146,16 +1137,16 @@ int mi355cg_get_recursive_residual(mi355cg_handle c, double* r) {
 }
 int mi355cg_get_true_residual(mi355cg_handle c, double* out) {
     if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
-    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one slab of a row-decomposed grid: use the mi355cg_dist_* entry points");
+    if (c->is_slab) return fail(MI355CG_ERR_STATE, "this handle owns one part of a decomposed grid: use the mi355cg_team_* / mi355cg_dist_* entry points");
     if (!c->solved) return fail(MI355CG_ERR_STATE, "no solve has run on this handle");
     HIPCK(hipSetDevice(c->device));
-    // residual = A x - b   (dirichlet_solver.cpp:147-161); scratch: A x in ap, difference in the inactive direction buffer
-    if (c->is_csr) launch_csr_spmv(c, c->x, c->ap, nullptr, nullptr, nullptr);
-    else launch_apply<double, 2>(c, c->x, c->ap);
-    double* scratch = c->p[c->cur ^ 1];
-    hipLaunchKernelGGL((k_sub<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->ap, c->b, scratch);
+    if (int rc = ensure_scratch(c)) return rc;
+    // residual = A x - b   (dirichlet_solver.cpp:147-161)
+    if (c->is_csr) launch_csr_spmv(c, c->x, c->scratch[0], nullptr, nullptr, nullptr);
+    else launch_apply<double, 2>(c, c->x, c->scratch[0], whole_part(c));
+    hipLaunchKernelGGL((k_sub<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->scratch[0], c->b, c->scratch[1]);
     HIPCK(hipGetLastError());
-    return download_packed<double>(c, scratch, out);
+    return download_packed<double>(c, c->scratch[1], out);
 }
 
 int mi355cg_set_profiling(mi355cg_handle c, int enable) {
@@ -1175,14 +1166,50 @@ int mi355cg_get_layout(mi355cg_handle c, long long* padded_len, int* pitch_botto
     if (padded_len) *padded_len = c->g.own_len;
     if (pitch_bottom) *pitch_bottom = c->g.Pb;
     if (pitch_upper) *pitch_upper = c->g.Pu;
-    if (grid_stencil) *grid_stencil = c->grid_stencil;
-    if (grid_update) *grid_update = c->grid_update;
-    if (rows_per_item) *rows_per_item = c->rows_per_item;
+    if (grid_stencil) *grid_stencil = c->whole.grid;
+    if (grid_update) *grid_update = c->whole.grid;
+    if (rows_per_item) *rows_per_item = c->whole.ty;
     return MI355CG_OK;
 }
 
+// ---- checksums (tests of large decomposed grids compare these instead of host copies of the vectors) -----------------
+namespace {
+struct hdd { double hi, lo; };
+inline hdd hdd_add(hdd a, hdd b) {                  // same TwoSum-based addition as the device's dd_add (no contraction: -ffp-contract=off)
+    const double s = a.hi + b.hi, bb = s - a.hi, e = (a.hi - (s - bb)) + (b.hi - bb);
+    const double lo = e + (a.lo + b.lo), hi = s + lo;
+    return hdd{hi, lo - (hi - s)};
+}
+// out[0] += sum of v, out[1] += sum of v^2 over the part's own cells, as double-double pairs.  Synchronises the part's stream.
+int ctx_checksum(mi355cg_ctx* c, int which, hdd out[2]) {
+    const double* v = which == 0 ? c->x : which == 1 ? c->r : which == 2 ? c->b : which == 3 ? c->u : nullptr;
+    if (!v) return fail(MI355CG_ERR_INVALID, "checksum: vector %d (0 x, 1 r, 2 b, 3 u)", which);
+    if (c->is_csr) return fail(MI355CG_ERR_INVALID, "checksum: grid handles only");
+    HIPCK(hipSetDevice(c->device));
+    if (c->is_slab) HIPCK(hipDeviceSynchronize());
+    if (which == 3) if (int rc = ensure_u_on_device(c)) return rc;
+    const int grid = 512;
+    hipLaunchKernelGGL((k_checksum<double, 2>), dim3(grid), dim3(kBlock), 0, c->stream, kernel_geom<double, 2>(c), c->whole.wl, v, c->partR);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * 4 * grid, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < grid; ++b) {
+        out[0] = hdd_add(out[0], hdd{c->partR_h[b], c->partR_h[grid + b]});
+        out[1] = hdd_add(out[1], hdd{c->partR_h[2 * grid + b], c->partR_h[3 * grid + b]});
+    }
+    return MI355CG_OK;
+}
+}  // namespace
 
-// ---- slab (one rank of a row-decomposed grid) ------------------------------------------------------
+int mi355cg_checksum(mi355cg_handle c, int which, double* out2) {
+    if (!c || !out2) return fail(MI355CG_ERR_INVALID, "null argument");
+    hdd s[2] = {{0, 0}, {0, 0}};
+    if (int rc = ctx_checksum(c, which, s)) return rc;
+    out2[0] = s[0].hi + s[0].lo; out2[1] = s[1].hi + s[1].lo;
+    return MI355CG_OK;
+}
+
+// ---- slab (one rank of a row-decomposed grid), driven phase by phase by the caller (iterative_solvers_amd/distributed.py) ----
 int mi355cg_slab_rows(int n, int world, int rank, int* y_lo, int* y_hi) {
     GridParams gp;
     if (!grid_params_init(&gp, n, n, 0, 1, 0, 1)) return fail(MI355CG_ERR_INVALID, "grid %d rejected", n);
@@ -1216,14 +1243,13 @@ int mi355cg_owned_range(mi355cg_handle c, long long* packed_begin, long long* pa
 // The dist entry points enqueue on the caller's stream, taken literally (NULL = HIP's default stream,
 // which is also torch's default stream), so they order with the caller's collectives and copies.
 static hipStream_t pick_stream(mi355cg_ctx*, void* stream) { return (hipStream_t)stream; }
-// Slab-mode iteration config: the same launch shapes as mi355cg_solve (7.5 words for REL_2NORM, 8 for MSG).
-static IterCfg dist_cfg(const mi355cg_ctx* c) {
-    IterCfg cfg = make_cfg(&c->dist_prm);
-    cfg.xfuse = c->xfuse && c->update_mode == 0 && c->dist_prm.rule == MI355CG_RULE_REL_2NORM && !cfg.has_u;
-    cfg.recomp = c->recompute && c->update_mode == 0 && (cfg.xfuse || c->dist_prm.rule == MI355CG_RULE_MSG_MAXNORM);
-    cfg.x2 = cfg.recomp && cfg.xfuse && c->x2step;
-    return cfg;
+// slots of a part's split launches: interior first, then edge
+static Where part_where(const mi355cg_ctx* c, hipStream_t st, int rows) {
+    if (rows == 1) return Where{st, &c->interior, 0};
+    if (rows == 2) return Where{st, &c->edge, c->interior.grid};
+    return Where{st, &c->whole, 0};
 }
+static int part_slots(const mi355cg_ctx* c, int rows) { return rows == 0 ? c->whole.grid : c->interior.grid + c->edge.grid; }
 
 int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream) {
     if (!c || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
@@ -1231,7 +1257,7 @@ int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream
     if (prm->diagnostics) return fail(MI355CG_ERR_INVALID, "per-iteration diagnostics are not available in slab mode");
     HIPCK(hipSetDevice(c->device));
     c->dist_prm = *prm; c->dist_active = true;
-    const IterCfg cfg = dist_cfg(c);
+    const IterCfg cfg = make_cfg(prm);
     if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
     hipStream_t st = pick_stream(c, stream);
     const size_t bytes = sizeof(double) * c->storage_len;
@@ -1241,8 +1267,8 @@ int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream
     HIPCK(hipMemsetAsync(c->ap, 0, bytes, st));
     HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, st));
     c->cur = 0;
-    c->nB_own = cfg.recomp ? c->grid_stencil : c->grid_update;
-    launch_update<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, /*init=*/true, st, own_partA(c));
+    c->nB_own = c->whole.grid;
+    launch_update_flat<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, st, c->whole.grid);
     HIPCK(hipGetLastError());
     c->solved = true;
     return MI355CG_OK;
@@ -1313,14 +1339,10 @@ int mi355cg_dist_scatter_ghosts(mi355cg_handle c, int vector, const double* gath
 // `estride` = doubles between consecutive ranks' sums in `gathered_B` (FB_COUNT, or the record width).
 int mi355cg_dist_stencil(mi355cg_handle c, const double* gathered_B, int nranks, int estride, int rows, void* stream) {
     if (!c || !c->dist_active || !gathered_B) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
-    const IterCfg cfg = dist_cfg(c);
-    StencilWhere w{pick_stream(c, stream), &c->wl, c->grid_stencil, 0};
-    if (rows == 1) w = StencilWhere{w.stream, &c->wl_int, c->grid_int, 0};
-    else if (rows == 2) w = StencilWhere{w.stream, &c->wl_edge, c->grid_edge, c->grid_int};
-    if (rows == 1 && c->wl_int.nitems == 0) return MI355CG_OK;
+    const IterCfg cfg = make_cfg(&c->dist_prm);
     const PartSrc pb{gathered_B, nranks, 1, estride};
-    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, c->ap, w, pb, c->x);
-    c->nA_dist = rows == 0 ? c->grid_stencil : c->grid_int + c->grid_edge;
+    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, part_where(c, pick_stream(c, stream), rows), pb);
+    c->nA_dist = part_slots(c, rows);
     HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
@@ -1329,30 +1351,19 @@ int mi355cg_dist_flip(mi355cg_handle c) {
     c->cur ^= 1;
     return MI355CG_OK;
 }
-// rows: as in mi355cg_dist_stencil.  The recomputing update (mi355cg_dist_update_reads_ghosts() != 0) evaluates A p again,
-// so its first and last owned row read the direction's ghost rows; a full update phase is then {0} or {1, 2}.
-// The flat update reads no ghost row: rows 0 and 1 run it over the whole slab, rows 2 is a no-op.
+// rows: as in mi355cg_dist_stencil.  The update rebuilds A p from the stored direction, so its first and last owned row
+// read the direction's ghost rows, which the stencil launch keeps up to date itself; a full update phase is {0} or {1, 2}.
 int mi355cg_dist_update(mi355cg_handle c, const double* gathered_A, int nranks, int estride, int rows, void* stream) {
     if (!c || !c->dist_active || !gathered_A) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run / null partials");
-    const IterCfg cfg = dist_cfg(c);
+    IterCfg cfg = make_cfg(&c->dist_prm);
     const PartSrc pa{gathered_A, nranks, 1, estride};
-    hipStream_t st = pick_stream(c, stream);
-    if (!cfg.recomp) {
-        if (rows != 2) launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, st, pa);
-    } else {
-        StencilWhere w{st, &c->wl, c->grid_stencil, 0};
-        if (rows == 1) w = StencilWhere{st, &c->wl_int, c->grid_int, 0};
-        else if (rows == 2) w = StencilWhere{st, &c->wl_edge, c->grid_edge, c->grid_int};
-        c->nB_own = rows == 0 ? c->grid_stencil : c->grid_int + c->grid_edge;
-        if (!(rows == 1 && c->wl_int.nitems == 0))
-            launch_update<double, 2>(c, cfg, c->x, c->r, c->p[c->cur], c->ap, c->u, false, st, pa, -1.0, &w, c->p[c->cur ^ 1]);
-    }
+    c->nB_own = part_slots(c, rows);
+    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, part_where(c, pick_stream(c, stream), rows), pa);
     HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
-// Non-zero if the caller has to deliver the direction's ghost rows before the update's edge rows run.  Always 0 now: the
-// stencil launch of a slab keeps the new direction in its two ghost rows itself (StencilArgs::store_ghosts), so the
-// recomputing update finds them locally and the direction never crosses ranks.
+// Non-zero if the caller has to deliver the direction's ghost rows before the update's edge rows run.  Always 0: the
+// stencil launch of a part keeps the new direction in its ghost rows itself (StencilArgs::store_ghosts).
 int mi355cg_dist_update_reads_ghosts(mi355cg_handle c) {
     (void)c;
     return 0;
@@ -1371,12 +1382,11 @@ int mi355cg_dist_check(mi355cg_handle c, const double* gathered_B, int nranks, i
 // that is still pending after an odd iteration count (REL_2NORM).  No-op otherwise.
 int mi355cg_dist_finish(mi355cg_handle c, void* stream) {
     if (!c || !c->dist_active) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run");
-    const IterCfg cfg = dist_cfg(c);
+    const IterCfg cfg = make_cfg(&c->dist_prm);
     const CgState fin = *c->summary_h;
     c->cur = fin.it & 1;                 // launches after the stop decision were no-ops but flipped the host-side index
-    if (cfg.xfuse && fin.it > 0 && (!cfg.x2 || (fin.it & 1))) {
-        hipLaunchKernelGGL((k_flush_x<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, pick_stream(c, stream),
-                           c->g.own_begin, c->g.own_len, c->x, c->p[c->cur], fin.alpha);
+    if (cfg.x2 && fin.it > 0 && (fin.it & 1)) {
+        launch_flush_x<double, 2>(c, c->whole, c->x, c->p[c->cur], fin.alpha, pick_stream(c, stream));
         HIPCK(hipGetLastError());
     }
     return MI355CG_OK;
@@ -1431,3 +1441,5 @@ int mi355cg_dist_halo_recv_counts(mi355cg_handle c, long long* n_from_lo, long l
 }
 
 }  // extern "C"
+
+#include "team.h"

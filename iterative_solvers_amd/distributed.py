@@ -332,6 +332,123 @@ class DistributedCG:
 
 
 # ---------------------------------------------------------------------------------------------
+def decompose(n: int, world: int, decomp: int = _capi.DECOMP_ROWS):
+    """[(y_lo, y_hi, x_lo, x_hi)] per part: rows inclusive, columns [x_lo, x_hi).  Pure host arithmetic."""
+    lib = _capi.load()
+    out = []
+    for r in range(world):
+        v = [C.c_int() for _ in range(4)]
+        rc = lib.mi355cg_decompose(n, world, decomp, r, *[C.byref(i) for i in v])
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(lib.mi355cg_last_error().decode())
+        _capi.check(rc)
+        out.append(tuple(i.value for i in v))
+    return out
+
+
+def halo_plan(n: int, world: int, decomp: int, rank: int):
+    """The halo messages of `rank` per iteration (dicts with id, peer, send, kind, y0, y1, x0, x1, count)."""
+    lib = _capi.load()
+    cnt = C.c_int()
+    _capi.check(lib.mi355cg_halo_plan(n, world, decomp, rank, 0, C.byref(cnt), None))
+    msgs = (_capi.HaloMsg * max(cnt.value, 1))()
+    _capi.check(lib.mi355cg_halo_plan(n, world, decomp, rank, cnt.value, C.byref(cnt), msgs))
+    return [{f: getattr(m, f) for f, _ in _capi.HaloMsg._fields_} for m in msgs[:cnt.value]]
+
+
+class Team:
+    """The native multi-GPU loop (csrc/team.h) over the C ABI.
+
+    Team.local(n, world, ...): this process drives every part (one or several GPUs).
+    Team.rccl(n, ...): one process per GPU; the library creates its own RCCL communicator, the 128-byte id travels
+    through torch.distributed (any backend) from rank 0."""
+
+    def __init__(self, handle, n):
+        self._lib = _capi.load()
+        self._h = handle
+        self.n = n
+        w, nl, dc, sz = C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
+        _capi.check(self._lib.mi355cg_team_info(self._h, C.byref(w), C.byref(nl), C.byref(dc), C.byref(sz)))
+        self.world, self.nlocal, self.decomp, self.size = w.value, nl.value, dc.value, sz.value
+
+    @classmethod
+    def local(cls, n, world, decomp=_capi.DECOMP_ROWS, devices=None, domain=(1.0, 2.0, 1.0, 2.0)):
+        lib = _capi.load()
+        h = C.c_void_p()
+        a, b, c, d = domain
+        devs = (C.c_int * len(devices))(*devices) if devices else None
+        rc = lib.mi355cg_team_create_local(n, n, a, b, c, d, world, devs, len(devices) if devices else 0, decomp, C.byref(h))
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(lib.mi355cg_last_error().decode())
+        _capi.check(rc)
+        return cls(h, n)
+
+    @classmethod
+    def rccl(cls, n, decomp=_capi.DECOMP_ROWS, device=None, group=None, domain=(1.0, 2.0, 1.0, 2.0)):
+        lib = _capi.load()
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ident = [None]
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            _capi.check(lib.mi355cg_team_unique_id(buf))
+            ident = [bytes(buf)]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(ident[0])
+        h = C.c_void_p()
+        a, b, c, d = domain
+        dev = torch.cuda.current_device() if device is None else device
+        rc = lib.mi355cg_team_create_rccl(n, n, a, b, c, d, world, rank, dev, idbuf, decomp, C.byref(h))
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(lib.mi355cg_last_error().decode())
+        _capi.check(rc)
+        return cls(h, n)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi355cg_team_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, params: _capi.Params, callback=None, stop_flag: Optional[C.c_int] = None) -> _capi.Results:
+        res = _capi.Results()
+        cb = _capi.ITER_CB(lambda user, it, p, r, e: callback(it, p, r, e)) if callback else _capi.ITER_CB()
+        sp = C.cast(C.pointer(stop_flag), C.c_void_p) if stop_flag is not None else None
+        rc = self._lib.mi355cg_team_solve(self._h, C.byref(params), cb, None, sp, C.byref(res))
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(self._lib.mi355cg_last_error().decode())
+        _capi.check(rc)
+        return res
+
+    def vector(self, which: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """which: 0 x, 1 recursive residual, 2 right-hand side, 3 exact solution.  Global packed order; only the entries
+        owned by this process's parts are written (all of them for a local team)."""
+        if out is None:
+            out = np.full(self.size, np.nan)
+        _capi.check(self._lib.mi355cg_team_get_vector(self._h, which, out))
+        return out
+
+    def checksum(self, which: int):
+        o = (C.c_double * 2)()
+        _capi.check(self._lib.mi355cg_team_checksum(self._h, which, o))
+        return o[0], o[1]
+
+    def set_profiling(self, on: bool):
+        _capi.check(self._lib.mi355cg_team_set_profiling(self._h, 1 if on else 0))
+
+    def phase_times(self):
+        k, c, w = C.c_double(), C.c_double(), C.c_double()
+        _capi.check(self._lib.mi355cg_team_phase_times(self._h, C.byref(k), C.byref(c), C.byref(w)))
+        return {"kernels_ms": k.value, "comm_ms": c.value, "wall_ms": w.value}
+
+
+# ---------------------------------------------------------------------------------------------
 def weak_scaling_n(n1: int, world: int) -> int:
     """Grid size whose unknown count is ~world x that of n1 (even)."""
     n = int(round(n1 * (world ** 0.5) / 2.0)) * 2

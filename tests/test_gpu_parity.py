@@ -322,15 +322,17 @@ def test_reference_iteration_counts_large(isa, N, iters):
 
 
 @pytest.mark.parametrize("N,max_it,sync", [(16, 10 ** 6, 200), (16, 10 ** 6, 7), (64, 33, 200), (64, 34, 8), (130, 10 ** 6, 50)])
-def test_x_update_folded_into_stencil_is_bit_identical(isa, N, max_it, sync, monkeypatch):
-    """REL_2NORM fast path (9 words/unknown: x += alpha*p rides in the NEXT stencil launch, last one
-    flushed after the loop) against the plain 10-word iteration: same arithmetic, so the same bits --
-    whatever the chunking, the stopping iteration's parity or an iteration cap."""
+def test_two_step_x_update_is_bit_identical_to_stepwise(isa, N, max_it, sync):
+    """REL_2NORM default path (7.5 words/unknown: x touched every second iteration, two steps at once, the last one
+    flushed after an odd count) against the path that updates x every iteration (the per-iteration diagnostics mode):
+    same arithmetic in the same order, so the same bits -- whatever the chunking, the stopping iteration's parity
+    or an iteration cap."""
     out = []
-    for xfuse in ("0", "1"):
-        monkeypatch.setenv("MI355CG_XFUSE", xfuse)
+    for stepwise in (False, True):
         s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
         sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-9, max_it)
+        if stepwise:
+            sol.setIterationCallback(lambda *a: None)
         x = sol.solve(sync_every=sync)
         out.append((x, sol.getIterations(), s._handle.recursive_residual(), sol.last_results.r_norm2))
     assert out[0][1] == out[1][1]

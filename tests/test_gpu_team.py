@@ -1,0 +1,150 @@
+"""GPU tests of the native multi-GPU loop (csrc/team.h, mi355cg_team_*): a LOCAL team drives all parts of a decomposition
+in one process on the one GPU of the test box -- the same kernels, records, halo messages, streams and events as the
+one-process-per-GPU RCCL team, with device-to-device copies in place of ncclSend/ncclRecv.  Every decomposition must
+reproduce the single-GPU solve BIT FOR BIT (the inner products travel as double-double pairs and are reduced in part
+order), and that solve is pinned to the CPU oracle by test_gpu_parity.py.
+
+BASELINE configs 4 (N = 16384, 2 x 2) and 5 (N = 32768, 8 parts) run here at full size for a bounded number of
+iterations: vectors of that size stay on the device, so the comparison uses device-side double-double checksums, the
+recursive-vs-true residual property, and the exact equality of the residual norms."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(isa, rule, **kw):
+    p = isa.default_params(rule)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _single(isa, n, rule, **kw):
+    s = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0)
+    cbs = []
+    res = s._handle.solve(_params(isa, rule, **kw), callback=(lambda *a: cbs.append(a)) if rule == 0 else None)
+    return s, res, cbs
+
+
+@pytest.mark.parametrize("n,world,decomp", [(64, 2, 0), (64, 3, 0), (130, 4, 0), (258, 4, 1), (258, 2, 1), (258, 8, 1), (514, 8, 1),
+                                            (1026, 4, 1), (1026, 8, 0), (66, 16, 0)])
+def test_local_team_rel2_is_bit_identical_to_one_gpu(n, world, decomp):
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    from oracle.oracle import OracleGrid
+    kw = dict(eps_rel=1e-8, max_iterations=10 ** 5)
+    s1, r1, _ = _single(isa, n, 1, **kw)
+    t = Team.local(n, world, decomp)
+    rt = t.solve(_params(isa, 1, **kw))
+    assert (rt.iterations, rt.converged, rt.stop_reason) == (r1.iterations, r1.converged, r1.stop_reason)
+    assert rt.r_norm2 == r1.r_norm2 and rt.initial_r_norm2 == r1.initial_r_norm2
+    x = t.vector(0)
+    assert not np.isnan(x).any()                                   # every unknown is owned by exactly one part ...
+    assert np.array_equal(x, s1._handle.solution())                # ... and holds the single-GPU bits
+    assert np.array_equal(t.vector(1), s1._handle.recursive_residual())
+    assert np.array_equal(t.vector(2), s1.get_rhs()) and np.array_equal(t.vector(3), s1.get_true_solution_vector())
+    assert t.checksum(0) == tuple(_cs(s1, 0)) and t.checksum(1) == tuple(_cs(s1, 1))
+    og = OracleGrid(n, n)
+    ref = og.mf_solve(eps=1e-8, max_iterations=10 ** 5)
+    assert rt.iterations == ref.iterations
+    assert abs(rt.r_norm2 - ref.r_norm) / ref.initial_r_norm <= 1e-12
+    t.close()
+
+
+def _cs(system, which):
+    from iterative_solvers_amd import _capi
+    o = (C.c_double * 2)()
+    _capi.check(_capi.load().mi355cg_checksum(system._handle._h, which, o))
+    return o[0], o[1]
+
+
+@pytest.mark.parametrize("n,world,decomp", [(64, 2, 0), (258, 4, 1), (130, 3, 0)])
+def test_local_team_msg_rule_callbacks_and_stop_reason(n, world, decomp):
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    from oracle.oracle import OracleGrid
+    kw = dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iterations=10 ** 5)
+    s1, r1, cb1 = _single(isa, n, 0, **kw)
+    t = Team.local(n, world, decomp)
+    cbs = []
+    rt = t.solve(_params(isa, 0, **kw), callback=lambda *a: cbs.append(a))
+    assert (rt.iterations, rt.converged, rt.stop_reason) == (r1.iterations, r1.converged, r1.stop_reason)
+    assert cbs == cb1                                              # iteration numbers and all three norms, exactly
+    assert (rt.final_residual_norm, rt.final_precision, rt.final_error_norm) == (r1.final_residual_norm, r1.final_precision, r1.final_error_norm)
+    assert np.array_equal(t.vector(0), s1._handle.solution())
+    ref = OracleGrid(n, n).msg_solve(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iterations=10 ** 5)
+    assert (rt.iterations, rt.stop_reason) == (ref.iterations, ref.stop_reason)
+    assert [c[0] for c in cbs] == [c[0] for c in ref.callbacks]
+    t.close()
+
+
+def test_team_stop_request_and_iteration_cap():
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    t = Team.local(130, 4, 1)
+    stop = C.c_int(0)
+
+    def cb(it, *_):
+        if it == 1:
+            stop.value = 1
+    res = t.solve(_params(isa, 0, eps_precision=1e-12, eps_residual=1e-12, eps_exact_error=-1.0, max_iterations=10 ** 5), callback=cb, stop_flag=stop)
+    assert res.stop_reason == 4 and res.iterations == 1 and not res.converged     # msg_solver.cpp:82-87
+    res = t.solve(_params(isa, 1, eps_rel=1e-30, max_iterations=37))
+    assert res.iterations == 37 and not res.converged
+    res = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 5))                              # the team is reusable
+    assert res.converged
+    t.close()
+
+
+def test_rccl_team_of_one_rank_runs_the_collectives():
+    """The RCCL transport (own communicator, ncclAllGather of the records on the comm stream, events) at world size 1 --
+    all this box can offer -- must reproduce the single-GPU solve exactly."""
+    import os
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    n = 258
+    kw = dict(eps_rel=1e-8, max_iterations=10 ** 5)
+    s1, r1, _ = _single(isa, n, 1, **kw)
+    os.environ["MI355CG_FORCE_COLLECTIVES"] = "1"
+    try:
+        t = Team.rccl(n, device=0)
+        rt = t.solve(_params(isa, 1, **kw))
+    finally:
+        os.environ.pop("MI355CG_FORCE_COLLECTIVES", None)
+    assert (rt.iterations, rt.r_norm2) == (r1.iterations, r1.r_norm2)
+    assert np.array_equal(t.vector(0), s1._handle.solution())
+    t.close()
+
+
+def _big(n, world, decomp, iters):
+    """Fixed-iteration run of a full-size config as a LOCAL team vs the single context, compared on the device."""
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    kw = dict(max_iterations=iters, fixed_iterations=1, sync_every=iters)
+    t = Team.local(n, world, decomp)
+    rt = t.solve(_params(isa, 1, **kw))
+    team = (rt.iterations, rt.r_norm2, rt.initial_r_norm2, t.checksum(0), t.checksum(1), t.checksum(2))
+    t.close()
+    s1, r1, _ = _single(isa, n, 1, **kw)
+    one = (r1.iterations, r1.r_norm2, r1.initial_r_norm2, _cs(s1, 0), _cs(s1, 1), _cs(s1, 2))
+    assert team == one, (team, one)
+    assert rt.r_norm2 < rt.initial_r_norm2
+    s1._handle.close()
+    return rt
+
+
+def test_config4_16384_as_2x2_team_matches_one_gpu():
+    """BASELINE config 4: N = 16384 (201 M unknowns), 2 x 2 decomposition, 30 iterations."""
+    _big(16384, 4, 1, 30)
+
+
+def test_config4_16384_as_4_row_slabs_matches_one_gpu():
+    _big(16384, 4, 0, 20)
+
+
+def test_config5_32768_as_8_parts_matches_one_gpu():
+    """BASELINE config 5: N = 32768 (805 M unknowns) over 8 parts (4 x 2), 12 iterations; 2 x 45 GB of vectors on the card."""
+    _big(32768, 8, 1, 12)

@@ -1,6 +1,6 @@
-"""The iteration has several launch shapes selected by environment knobs read at context creation
-(DESIGN.md section 4).  Every shape must take bit-identical CG steps: same iteration count, same recursive residual norm,
-same x as the default path -- and the default path is pinned to the oracle by test_gpu_parity.py."""
+"""The launch geometry (item height, waves, rows in flight) is selected by environment knobs read at context creation
+(DESIGN.md section 4).  Every geometry must take bit-identical CG steps: same iteration count, same recursive residual norm,
+same x as the default -- and the default is pinned to the oracle by test_gpu_parity.py."""
 import os
 
 import numpy as np
@@ -9,14 +9,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [
-    {},                                                     # default: A p recomputed, x every second iteration (7.5 words)
-    {"MI355CG_X2STEP": "0"},                                # x update folded into every stencil launch (8 words)
-    {"MI355CG_RECOMPUTE": "0"},                             # A p stored and streamed back (9 words)
-    {"MI355CG_RECOMPUTE": "0", "MI355CG_XFUSE": "0"},       # separate 4 + 6 word launches (10 words)
-    {"MI355CG_SDEPTH": "4", "MI355CG_UDEPTH": "4", "MI355CG_UDEPTH_FULL": "4", "MI355CG_MSG_DEPTH": "4"},
-    {"MI355CG_UPDATE_DESC": "0"},
-    {"MI355CG_ROWS": "7"},                                  # odd item height, several rounds per wave
-    {"MI355CG_STENCIL_BLOCKS": "37"},
+    {},                                                     # default: ~32-row items dealt round-robin to 2 048 waves, 2 rows in flight
+    {"MI355CG_ITEM_ROWS": "7"},                             # odd item height, many rounds per wave
+    {"MI355CG_ITEM_ROWS": "1"},                             # every item fetches 3 rows and computes 1: the fetch cursor is always in the next item
+    {"MI355CG_ITEM_ROWS": "1000000"},                       # one tall item per wave (round 1's shape)
+    {"MI355CG_DEPTH": "3"},                                 # 3 rows in flight
+    {"MI355CG_DEPTH": "3", "MI355CG_ITEM_ROWS": "1"},
+    {"MI355CG_BLOCKS": "37"},
+    {"MI355CG_WAVES": "256", "MI355CG_ITEM_ROWS": "5"},
 ]
 
 
