@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- CG iterations/second and achieved HBM GB/s of the matrix-free CG hot path.
 
-A "step" is one CG iteration (fused stencil kernel A' + fused update kernel B) on the
-BASELINE config-2 workload: N x N = 4096 x 4096 intervals on the L-shaped domain, fp64,
-U = 12 574 721 unknowns per GPU, deterministic synthetic RHS (the reference's f and Dirichlet
-data), x0 = 0, convergence tests disabled so that exactly K iterations are timed.
+A "step" is one CG iteration (fused stencil launch A' + fused update launch B).  Default workload = BASELINE
+config 2: N x N = 4096 x 4096 intervals on the L-shaped domain, fp64, U = 12 574 721 unknowns, deterministic synthetic
+RHS (the reference's f and Dirichlet data), x0 = 0, convergence tests disabled so that exactly K iterations are timed.
 
   python bench.py --gpus 1 --steps 2000 --warmup 200
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (weak scaling:
-      every rank owns a 4096-interval-class slab; the global grid grows with N)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+      weak scaling (default): every rank owns a config-2-sized part, the global grid grows with N
+      --scaling strong --grid 32768: BASELINE config 5's fixed grid cut into N parts
+      --decomp rows | 2d: row slabs, or (N/2) x 2 blocks (config 4's "2 x 2" at N = 4)
 
-Prints ONE JSON line (rank 0).  value = total CG iterations/s of the job; hbm_gbps uses the
-ALGORITHMIC bytes of SURVEY 8d (88 B per unknown per iteration, fp64).
+Prints ONE JSON line (rank 0).  `value` = CG iterations/s of the whole job (weak scaling: in units of config-2-sized
+parts advanced per second), timed on the host around K iterations between device synchronisations; `hbm_gbps` = bytes the
+iteration really moves (60 B per unknown for the REL_2NORM loop) per second; the per-kernel roofline comes from HIP events.
 """
 from __future__ import annotations
 
@@ -25,19 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured-achievable
-ALG_BYTES_PER_UNKNOWN = 88.0    # 11 words fp64 per unknown per iteration
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured-achievable (float4 copy, guide)
+SURVEY_BYTES_PER_UNKNOWN = 88.0  # SURVEY 8d's convention: 11 words per unknown per iteration (textbook three-phase CG)
 # Compulsory words per unknown and launch of THIS implementation -- what roofline.achieved counts.
-# Default REL_2NORM (A p recomputed in the update launch, never stored; x updated every second iteration, two steps at
-# once): stencil launch = read r,p / write p = 3; update launch = read p,r / write r = 3 on odd iterations and
-# read p,p_prev,r,x / write r,x = 6 on even ones, 4.5 on average (7.5 per iteration).
-# MSG: stencil read r,p / write p = 3, update read p,r,x / write r,x = 5.
-# MI355CG_X2STEP=0: REL_2NORM 5 + 3.  MI355CG_RECOMPUTE=0: REL_2NORM 6 + 3 (A p stored and streamed back), MSG or MI355CG_XFUSE=0: 4 + 6.
-KERNEL_ALG_WORDS_X2 = {"stencil": 3, "update": 4.5}
-KERNEL_ALG_WORDS_RECOMP = {"stencil": 5, "update": 3}
-KERNEL_ALG_WORDS_RECOMP_MSG = {"stencil": 3, "update": 5}
-KERNEL_ALG_WORDS_XFUSE = {"stencil": 6, "update": 3}
-KERNEL_ALG_WORDS_PLAIN = {"stencil": 4, "update": 6}
+# REL_2NORM: stencil launch reads r, p and writes p = 3; update launch reads p, r and writes r = 3 on odd iterations,
+# reads p, p_prev, r, x and writes r, x = 6 on even ones: 4.5 on average, 7.5 per iteration.  MSG: 3 + 5 (x every iteration).
+WORDS = {"rel2": {"stencil": 3, "update": 4.5}, "msg": {"stencil": 3, "update": 5}}
 
 
 def unknowns(n: int) -> int:
@@ -75,13 +70,102 @@ def cpu_baseline(n: int, iters: int):
 
 
 def read_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    """HBM bytes per launch of the kernels from the committed rocprofv3 PMC summary (N = 4096 fp64 only)."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             return json.load(f)
     except Exception:
         return None
+
+
+def bench_team(args, rule):
+    """N > 1: one process per GPU, the native RCCL team (csrc/team.h)."""
+    import torch
+    import torch.distributed as dist
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd import _capi
+    from iterative_solvers_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "RANK" not in os.environ:                            # started without a launcher: one rank, still through RCCL
+        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+        os.environ.setdefault("MASTER_PORT", "29531")
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    strong = args.scaling == "strong"
+    n = args.n if strong else D.weak_scaling_n(args.n, world)
+    U1, U = unknowns(args.n), unknowns(n)
+    decomp = _capi.DECOMP_2D if args.decomp == "2d" else _capi.DECOMP_ROWS
+    boxes = D.decompose(n, world, decomp)
+
+    path, note = "native RCCL team (csrc/team.h: ncclAllGather of 16-double records + neighbour ncclSend/ncclRecv on a second stream)", None
+    team = cg = None
+    try:
+        team = D.Team.rccl(n, decomp, device=local_rank)
+    except Exception as e:                                  # keep the scaling run alive: the torch.distributed driver of round 1
+        note = f"native team unavailable ({repr(e)[:160]}); fell back to the torch.distributed driver over row slabs"
+        path = "torch.distributed driver (iterative_solvers_amd/distributed.py DistributedCG, halo=p2p)"
+        y_lo, y_hi = D.slab_rows(n, world, rank)
+        cg = D.DistributedCG(D.SlabEngine(n, y_lo, y_hi, device=local_rank), halo="p2p")
+
+    def run(iters):
+        p = isa.default_params(rule)
+        p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = iters, 1, 0, 0, 500
+        return team.solve(p) if team else cg.solve(p)
+
+    run(args.warmup)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    res = run(args.steps)
+    torch.cuda.synchronize(); dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=torch.device("cuda", local_rank))
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    assert res.iterations == args.steps
+    its = args.steps / dt
+    phases = None
+    if team:
+        team.set_profiling(True)
+        run(min(args.steps, 200))
+        team.set_profiling(False)
+        phases = team.phase_times()
+        phases["driver_and_wait_ms"] = max(0.0, phases["wall_ms"] - phases["kernels_ms"])
+        phases["note"] = "rank 0, per iteration: device time of its kernels; device time of the collectives + halo messages on the comm stream (they overlap the kernels); wall"
+    bytes_it = 8.0 * sum(WORDS[args.rule].values())
+    units = 1.0 if strong else U / U1
+    moved = bytes_it * U * its / 1e9 / world
+    out = {
+        "metric": "cg_iters_per_sec", "value": round(its * units, 2), "unit": "iters/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"{n}x{n} L-shaped Dirichlet Poisson fp64 cut into {world} parts, matrix-free CG, fixed {args.steps} iterations"
+                                if strong else
+                                f"{n}x{n} L-shaped Dirichlet Poisson fp64 over {world} parts of ~{U1} unknowns (config-2 size per GPU), matrix-free CG, fixed {args.steps} iterations"),
+                   "n": n, "unknowns": U, "unknowns_per_gpu": U / world, "rule": args.rule,
+                   "value_is": "global CG iterations/s" if strong else "global CG iterations/s x (unknowns / config-2 unknowns) = config-2-sized part iterations/s",
+                   "decomposition": {"kind": "2d" if decomp else "rows", "parts": boxes},
+                   "parallelism": f"{'(N/2) x 2 blocks' if decomp else 'row slabs'} x{world}, one process per GPU, {path}"},
+        "global_iters_per_sec": round(its, 2),
+        "hbm_gbps": round(bytes_it * U * its / 1e9, 1),
+        "hbm_gbps_is": f"bytes really moved, summed over GPUs: {bytes_it:.0f} B per unknown per iteration",
+        "algorithmic_equivalent_gbps_88B": round(SURVEY_BYTES_PER_UNKNOWN * U * its / 1e9, 1),
+        "phases_ms": phases,
+        # whole-iteration roofline per GPU (kernels + collectives + driver); the per-kernel figures are in the 1-GPU bench line
+        "roofline": {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(moved / HBM_PEAK_GBPS, 4),
+                     "traffic": None, "scope": "bytes one GPU has to move per iteration / wall time per iteration, collectives included"},
+    }
+    if note:
+        out["note"] = note
+    dist.barrier()
+    if team:
+        team.close()
+    if "TORCHELASTIC_RUN_ID" not in os.environ and world == 1:
+        dist.destroy_process_group()                          # started without a launcher: leave nothing behind
+    return out
 
 
 def main():
@@ -89,10 +173,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid intervals per side on one GPU")
+    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid intervals per side (per GPU for weak scaling)")
     ap.add_argument("--rule", choices=["rel2", "msg"], default="rel2")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
                     help="f32 = BASELINE config 3: the fp32-storage inner CG of the mixed-precision path (use --grid 8192)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak (part size fixed) or strong (--grid fixed)")
+    ap.add_argument("--decomp", choices=["rows", "2d"], default="rows", help="N > 1: row slabs or (N/2) x 2 blocks")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     args = ap.parse_args()
@@ -110,8 +196,7 @@ def main():
     rule = _capi.RULE_REL_2NORM if args.rule == "rel2" else _capi.RULE_MSG_MAXNORM
 
     if world > 1 or args.gpus > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1":
-        from iterative_solvers_amd import distributed as dist_cg
-        out = dist_cg.bench(args, rule)
+        out = bench_team(args, rule)
         if rank == 0:
             print(json.dumps(out))
         return
@@ -136,44 +221,34 @@ def main():
     run(args.warmup, False)                                   # untimed warm-up iterations
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = run(args.steps, False)                              # exactly K iterations (plus the init pass)
+    res = run(args.steps, False)                              # exactly K iterations (plus the initialisation pass of a solve)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert res.iterations == args.steps, (res.iterations, args.steps)
     its = args.steps / dt
+    its_loop = args.steps / res.loop_seconds if res.loop_seconds > 0 else None     # HIP events around the K iterations alone
 
+    words = WORDS[args.rule]
+    words_iter = sum(words.values())
     roofline = None
     if not args.no_roofline_pass:
         # same loop again with a HIP-event pair around every launch on the solve stream
         k = min(args.steps, 500)
         run(k, True)
-        xfuse = args.rule == "rel2" and os.environ.get("MI355CG_XFUSE", "1") != "0"
-        recomp = os.environ.get("MI355CG_RECOMPUTE", "1") != "0" and (xfuse or args.rule == "msg")
-        x2 = recomp and xfuse and os.environ.get("MI355CG_X2STEP", "1") != "0"
-        if x2:
-            KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_X2
-        elif recomp:
-            KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_RECOMP if xfuse else KERNEL_ALG_WORDS_RECOMP_MSG
-        else:
-            KERNEL_ALG_WORDS = KERNEL_ALG_WORDS_XFUSE if xfuse else KERNEL_ALG_WORDS_PLAIN
-        words_iter = sum(KERNEL_ALG_WORDS.values())
         t = {name: h.kernel_time(i) for i, name in enumerate(("stencil", "update"))}
         dom = max(t, key=lambda name: t[name][0] * t[name][1])
         ms, launches = t[dom]
-        alg = KERNEL_ALG_WORDS[dom] * wbytes * U
+        alg = words[dom] * wbytes * U
         achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        tr = read_traffic()
-        kname = {"stencil": "k_stencil", "update": "k_update_st" if recomp else "k_update"}[dom]
+        tr = read_traffic() if (n == 4096 and not f32 and args.rule == "rel2") else None
+        kname = {"stencil": "k_stencil", "update": "k_update_st"}[dom]
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_6290": round(achieved / 6290.0, 4),
                     "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
-                    "alg_bytes_per_launch": alg, "alg_words_per_unknown": KERNEL_ALG_WORDS[dom],
-                    # what the whole iteration really has to move in this implementation, and the rate that is
-                    "words_per_unknown_per_iteration": words_iter,
-                    "alg_words": KERNEL_ALG_WORDS,
-                    "moved_gbps_per_iteration": round(words_iter * wbytes * U * its / 1e9, 1),
+                    "alg_bytes_per_launch": alg, "alg_words_per_unknown": words[dom],
+                    "words_per_unknown_per_iteration": words_iter, "alg_words": words,
                     "other": {name: {"avg_ms": round(t[name][0], 5),
-                                     "achieved": round(KERNEL_ALG_WORDS[name] * wbytes * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}
+                                     "achieved": round(words[name] * wbytes * U / (t[name][0] * 1e-3) / 1e9, 1) if t[name][0] > 0 else 0}
                               for name in t}}
 
     out = {
@@ -182,12 +257,16 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson {'fp32 inner CG of the mixed-precision path' if f32 else 'fp64'}, matrix-free CG, fixed {args.steps} iterations",
                    "n": n, "unknowns": U, "rule": args.rule, "layout": h.layout()},
-        # SURVEY 8d's convention: 11 words (88 B fp64) per unknown and iteration, the compulsory traffic of textbook
-        # three-phase CG.  This implementation moves fewer words (roofline.words_per_unknown_per_iteration), so the
-        # figure can exceed the 8 TB/s pin rate: it is an algorithmic equivalent, not bytes on the bus -- those are
-        # roofline.moved_gbps_per_iteration and the per-kernel roofline.achieved.
-        "hbm_gbps": round(ALG_BYTES_PER_UNKNOWN * (wbytes / 8.0) * U * its / 1e9, 1),
-        "hbm_gbps_convention": "88 B (fp64) / 44 B (fp32) per unknown per iteration (SURVEY 8d); see roofline.moved_gbps_per_iteration for bytes really moved",
+        "timing": "host clock around one solve of K iterations between device synchronisations (includes the solve's initialisation pass: "
+                  "3 memsets, r = b, ||r0||, two polls ~ 0.2 ms); loop_only_* = HIP events around the K iterations on the solve stream",
+        "loop_only_iters_per_sec": round(its_loop, 2) if its_loop else None,
+        "loop_only_ms_per_step": round(1e3 * res.loop_seconds / args.steps, 5) if its_loop else None,
+        # bytes the iteration really moves in this implementation: never above the HBM pin rate
+        "hbm_gbps": round(words_iter * wbytes * U * its / 1e9, 1),
+        "hbm_gbps_is": f"bytes really moved: {words_iter} words = {words_iter * wbytes:.0f} B per unknown per iteration",
+        # SURVEY 8d's convention (11 words = 88 B fp64 per unknown and iteration, textbook three-phase CG): an algorithmic
+        # equivalent, NOT bus bytes -- 3.5 of those 11 words are no longer moved here, so it may exceed the pin rate
+        "algorithmic_equivalent_gbps_88B": round(SURVEY_BYTES_PER_UNKNOWN * (wbytes / 8.0) * U * its / 1e9, 1),
         "roofline": roofline,
     }
     if args.cpu_iters > 0 and not f32:

@@ -90,6 +90,8 @@ typedef struct mi355cg_results {
     double solve_seconds;         /* wall time of the device loop (init .. last poll)            */
     double refine_true_rel;       /* F32_MIXED: final fp64 ||b-Ax||_2/||b||_2, else 0            */
     int    refine_outer;          /* F32_MIXED: outer refinement steps, else 0                   */
+    double loop_seconds;          /* device time of the iterations alone (HIP events on the solve stream: after the
+                                     initialisation pass .. after the last launch); 0 where not measured          */
 } mi355cg_results;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

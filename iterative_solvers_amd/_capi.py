@@ -46,7 +46,7 @@ class Results(C.Structure):
                 ("final_residual_norm", C.c_double), ("final_precision", C.c_double),
                 ("final_error_norm", C.c_double), ("r_norm2", C.c_double),
                 ("initial_r_norm2", C.c_double), ("solve_seconds", C.c_double),
-                ("refine_true_rel", C.c_double), ("refine_outer", C.c_int)]
+                ("refine_true_rel", C.c_double), ("refine_outer", C.c_int), ("loop_seconds", C.c_double)]
 
 
 class HaloMsg(C.Structure):

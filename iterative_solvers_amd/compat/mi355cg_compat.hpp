@@ -291,7 +291,7 @@ public:
         if (!a.context()) throw std::runtime_error("MSGSolver: the matrix is not a GridSystem operator");
         mi355cg_handle h = a.context()->h;
         mi355cg_compat::check(mi355cg_set_rhs(h, b.data()));
-        if (a.context()->csr && true_solution.extent(0) > 0)       // a generic matrix has no built-in exact solution
+        if (true_solution.extent(0) > 0)       // the error norms use the vector that was passed in (msg_solver.cpp:64-72,132-139)
             mi355cg_compat::check(mi355cg_set_true_solution(h, true_solution.data()));
         mi355cg_params p;
         mi355cg_default_params(&p, MI355CG_RULE_MSG_MAXNORM);
@@ -408,9 +408,10 @@ public:
     std::string getName() const { return name; }
 
     std::vector<double> solve(const std::vector<double>& true_solution) {        // matrix_free_system.cpp:383-482
-        (void)true_solution;                                                      // the context holds u of this grid
         mi355cg_handle h = system.context()->h;
         mi355cg_compat::check(mi355cg_set_rhs(h, b.data()));
+        if (true_solution.size() == b.size() && !true_solution.empty())           // :451-455 measures the error against the caller's vector
+            mi355cg_compat::check(mi355cg_set_true_solution(h, true_solution.data()));
         mi355cg_params p;
         mi355cg_default_params(&p, MI355CG_RULE_REL_2NORM);
         p.max_iterations = maxIterations; p.eps_rel = eps;

@@ -110,6 +110,7 @@ struct mi355cg_ctx {
     std::vector<ChunkGraph> graphs;
     int use_graph = -1;                 // env MI355CG_GRAPH: -1 auto (small grids), 0 off, 1 on
 
+    hipEvent_t ev_loop[2] = {nullptr, nullptr};   // brackets the iterations of the last solve (mi355cg_results::loop_seconds)
     bool profiling = false;
     EventPool events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pairs[2];
@@ -193,28 +194,31 @@ long long add_panel(WorkList& wl, int y0, int y1, int s0, int s1, int ty, int gc
     return (long long)rows * ns;
 }
 
-// Launch shape for a list of rectangles.  2 048 resident waves (2 workgroups per CU: 8 waves per CU already saturate
-// the memory system, round 1) take the items round-robin, MI355CG_ITEM_ROWS rows each (default 32): short items keep the
-// waves of a round inside one band of rows (see "work items" in cg_kernels.h).  The item height is then nudged so that
-// the item count fills a whole number of rounds -- a last round with a few items would run at a fraction of the chip.
-Plan make_plan(const std::vector<Rect>& rects, int fixed_ty = 0) {
+// Launch shape for a list of rectangles.  2 048 resident waves (2 workgroups per CU: 8 waves per CU already saturate the
+// memory system, round 1) take the items round-robin.  Measured (tools/tune.py, profiles/r02_tune_notes.md): one round of
+// items "as tall as it takes" is the best fp64 shape up to ~800 rows per item (N <= 16384 on one GPU); taller items (3 136 rows
+// of a 262 KB pitch at N = 32768: every wave sweeps 0.8 GB per stream) lose 14-16 %, so the height is capped and the rest
+// becomes further rounds -- which cost nothing since the load pipeline no longer drains between items.  The fp32 kernels
+// (256-column strips) like 64 rows.  The height is then nudged so that the items fill a whole number of rounds: a last
+// round with a few items would run at a fraction of the chip.
+Plan make_plan(const std::vector<Rect>& rects, int max_rows, int fixed_ty = 0) {
     Plan pl{};
     const int target_waves = std::max(kWaves, env_int("MI355CG_WAVES", 2048));
     const int max_blocks = std::max(1, env_int("MI355CG_BLOCKS", 512));
     const int waves = std::min(target_waves, max_blocks * kWaves);
-    const int item_rows = std::max(1, env_int("MI355CG_ITEM_ROWS", 32));
+    const long long item_rows = std::max(1, env_int("MI355CG_ITEM_ROWS", max_rows));
     long long strip_rows = 0;
     WorkList dry{};
     for (auto& r : rects) strip_rows += add_panel(dry, r.y0, r.y1, r.s0, r.s1, 0, 0);
     if (strip_rows == 0) return pl;
     int ty = fixed_ty;
     if (ty <= 0) {
-        const long long rounds = std::max<long long>(1, (strip_rows + (long long)waves * item_rows / 2) / ((long long)waves * item_rows));
+        const long long rounds = std::max<long long>(1, (strip_rows + waves * item_rows - 1) / (waves * item_rows));
         ty = (int)std::max<long long>(std::min<long long>(8, item_rows), (strip_rows + rounds * waves - 1) / (rounds * waves));
         for (int tries = 0; tries < 64; ++tries) {
             pl.wl = WorkList{};
             for (auto& r : rects) add_panel(pl.wl, r.y0, r.y1, r.s0, r.s1, ty, r.gc);
-            if (pl.wl.nitems <= rounds * waves || (tries == 0 && pl.wl.nitems <= waves)) break;
+            if (pl.wl.nitems <= rounds * waves) break;
             ++ty;
         }
     } else {
@@ -224,6 +228,7 @@ Plan make_plan(const std::vector<Rect>& rects, int fixed_ty = 0) {
     pl.grid = std::max(1, std::min(max_blocks, (pl.wl.nitems + kWaves - 1) / kWaves));
     return pl;
 }
+constexpr int kMaxRowsF64 = 800, kMaxRowsF32 = 64;
 
 void build_plans(mi355cg_ctx* c) {
     const Geom& g = c->g;
@@ -231,7 +236,7 @@ void build_plans(mi355cg_ctx* c) {
     Rect rr[2];
     const int nr = region_rects(gp, 2, g.y_lo, g.y_hi, c->s_lo, c->s_hi, rr);
     std::vector<Rect> whole(rr, rr + nr);
-    c->whole = make_plan(whole);
+    c->whole = make_plan(whole, kMaxRowsF64);
     c->has_gc = false;
     for (auto& r : whole) if (r.gc) c->has_gc = true;
     // split for halo / compute overlap: `edge` = everything that reads ghost data of r (first and last owned row, the
@@ -248,9 +253,9 @@ void build_plans(mi355cg_ctx* c) {
         if (r.gc & 1) cols.push_back(Rect{yi0, yi1, r.s0, r.s0 + 1, 1});
         if (r.gc & 2) cols.push_back(Rect{yi0, yi1, r.s1 - 1, r.s1, 2});
     }
-    c->interior = make_plan(inner);
+    c->interior = make_plan(inner, kMaxRowsF64);
     // edge rows are single-row items; edge strips are cut like the interior
-    Plan e_rows = make_plan(rows, 1), e_cols = make_plan(cols, c->interior.ty > 0 ? c->interior.ty : 0);
+    Plan e_rows = make_plan(rows, kMaxRowsF64, 1), e_cols = make_plan(cols, kMaxRowsF64, c->interior.ty > 0 ? c->interior.ty : 0);
     c->edge = e_rows;
     for (int k = 0; k < e_cols.wl.np && c->edge.wl.np < kMaxPanels; ++k) {
         Panel P = e_cols.wl.p[k];
@@ -263,7 +268,7 @@ void build_plans(mi355cg_ctx* c) {
     if (c->dtype == MI355CG_F32_MIXED) {                  // the fp32 kernels use 256-column strips (float4 per lane) on the same pitches
         Rect r4[2];
         const int n4 = region_rects(gp, 4, g.y_lo, g.y_hi, 0, strips_total(gp, 4), r4);
-        c->whole32 = make_plan(std::vector<Rect>(r4, r4 + n4));
+        c->whole32 = make_plan(std::vector<Rect>(r4, r4 + n4), kMaxRowsF32);
     }
     c->depth = env_int("MI355CG_DEPTH", 2) == 3 ? 3 : 2;
     c->use_graph = env_int("MI355CG_GRAPH", -1);
@@ -880,6 +885,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (c->partR_h) hipHostFree(c->partR_h);
     clear_graphs(c);
     c->events.destroy();
+    for (hipEvent_t e : c->ev_loop) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -997,6 +1003,8 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     if (int rc = poll()) return rc;
     const double initial_rnorm2 = c->summary_h->rnorm2;
     if (msg && cb) cb(user, 0, DBL_MAX, c->summary_h->rmax, cfg.has_u ? c->summary_h->emax : DBL_MAX);   // msg_solver.cpp:75-77
+    if (!c->ev_loop[0]) { HIPCK(hipEventCreate(&c->ev_loop[0])); HIPCK(hipEventCreate(&c->ev_loop[1])); }
+    HIPCK(hipEventRecord(c->ev_loop[0], c->stream));
 
     // The reference recomputes ||x - u|| every iteration (msg_solver.cpp:132-139), but the value is only
     // observable through the exact-error criterion, the periodic callbacks and the final report: read u
@@ -1082,6 +1090,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         }
         it_done = it_now;
     }
+    HIPCK(hipEventRecord(c->ev_loop[1], c->stream));
     CgState fin = *c->summary_h;
     // Launches enqueued after the stop decision return in their prologue but still flipped c->cur on the
     // host: the direction of the last REAL iteration is p[it % 2] (the solve starts with cur = 0).
@@ -1118,6 +1127,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     res.r_norm2 = fin.rnorm2;
     res.initial_r_norm2 = initial_rnorm2;
     res.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    { float ms = 0; HIPCK(hipEventSynchronize(c->ev_loop[1])); if (hipEventElapsedTime(&ms, c->ev_loop[0], c->ev_loop[1]) == hipSuccess) res.loop_seconds = 1e-3 * ms; }
     if (msg && cb) cb(user, res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm);   // msg_solver.cpp:193-195
     if (out) *out = res;
     return MI355CG_OK;

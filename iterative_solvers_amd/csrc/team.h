@@ -435,14 +435,20 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     int sync_every = std::min(prm->sync_every > 0 ? prm->sync_every : (msg ? 100 : 200), kHist);
     int it_done = 0;
     bool interrupted = false, first_chunk = cb != nullptr || stop_flag != nullptr;
+    if (!lead.c->ev_loop[0]) { HIPCK(hipEventCreate(&lead.c->ev_loop[0])); HIPCK(hipEventCreate(&lead.c->ev_loop[1])); }
+    HIPCK(hipSetDevice(lead.c->device));
+    HIPCK(hipEventRecord(lead.c->ev_loop[0], lead.c->stream));
     while (!lead.c->summary_h->done) {
-        // A stop request reaches every rank through the update records (a rank that left the loop alone would leave the
-        // others waiting in a collective): the flag read here travels with the next chunk and is seen by all at its poll.
-        if (stop_flag && *stop_flag) *t->stop_h = 1;
-        if (lead.c->summary_h->pad_) { interrupted = true; break; }
+        // A stop request has to reach every rank at the same iteration (a rank that left the loop alone would leave the
+        // others waiting in a collective).  One process: act on it at once, like the reference's per-iteration check
+        // (msg_solver.cpp:82-87).  Several: the flag travels with the update records of ONE more iteration and every rank
+        // finds it in its summary at the poll that follows.
+        const bool want_stop = stop_flag && *stop_flag;
+        if (lead.c->summary_h->pad_ || (want_stop && (!t->rccl || t->world == 1))) { interrupted = true; break; }
+        if (want_stop) *t->stop_h = 1;
         int m = std::min(sync_every, prm->max_iterations - it_done);
         if (msg && every > 0) m = std::min(m, every - it_done % every);
-        if (first_chunk) { m = 1; first_chunk = false; }
+        if (first_chunk || want_stop) { m = 1; first_chunk = false; }
         if (m <= 0) m = 1;
         for (int k = 0; k < m; ++k) {
             // ---- stencil phase ----
@@ -496,6 +502,8 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         }
         it_done = it_now;
     }
+    HIPCK(hipSetDevice(lead.c->device));
+    HIPCK(hipEventRecord(lead.c->ev_loop[1], lead.c->stream));
     const CgState fin = *lead.c->summary_h;
     for (auto& p : t->parts) {
         mi355cg_ctx* c = p.c;
@@ -528,6 +536,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     res.final_error_norm = cfg.has_u ? fin.emax : DBL_MAX;
     res.r_norm2 = fin.rnorm2; res.initial_r_norm2 = initial_rnorm2;
     res.solve_seconds = wall;
+    { float ms = 0; if (hipEventElapsedTime(&ms, lead.c->ev_loop[0], lead.c->ev_loop[1]) == hipSuccess) res.loop_seconds = 1e-3 * ms; }
     if (msg && cb) cb(user, res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm);
     if (out) *out = res;
     return MI355CG_OK;

@@ -453,62 +453,3 @@ def weak_scaling_n(n1: int, world: int) -> int:
     """Grid size whose unknown count is ~world x that of n1 (even)."""
     n = int(round(n1 * (world ** 0.5) / 2.0)) * 2
     return max(n, 6)
-
-
-def bench(args, rule: int) -> dict:
-    """bench.py's N > 1 leg: weak scaling, every rank owns ~ the config-2 number of unknowns."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if "RANK" not in os.environ:                            # started without a launcher: one rank, still through RCCL
-        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
-        os.environ.setdefault("MASTER_PORT", "29531")
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n = weak_scaling_n(args.n, world)
-    U1 = (args.n // 2 - 1) * (3 * args.n // 2 - 1)
-    U = (n // 2 - 1) * (3 * n // 2 - 1)
-    y_lo, y_hi = slab_rows(n, world, rank)
-    eng = SlabEngine(n, y_lo, y_hi, device=local_rank)
-    halo = os.environ.get("MI355CG_HALO", "gather")
-    cg = DistributedCG(eng, halo=halo)
-
-    def run(iters):
-        p = default_params(rule)
-        p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = iters, 1, 0, 0, 500
-        return cg.solve(p)
-
-    run(args.warmup)
-    torch.cuda.synchronize(); dist.barrier()
-    t0 = time.perf_counter()
-    res = run(args.steps)
-    torch.cuda.synchronize(); dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=eng.device)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    assert res.iterations == args.steps
-    its = args.steps / dt
-    slab_units = U / U1                                     # config-2-sized slabs advanced per iteration
-    out = {
-        "metric": "cg_iters_per_sec", "value": round(its * slab_units, 2), "unit": "iters/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson fp64 over {world} row slabs of ~{U1} unknowns "
-                               f"(config-2 size per GPU), matrix-free CG, fixed {args.steps} iterations",
-                   "n": n, "unknowns": U, "unknowns_per_gpu": U / world, "rule": args.rule,
-                   "value_is": "global CG iterations/s x (unknowns / config-2 unknowns) = config-2-sized slab iterations/s",
-                   "parallelism": f"row-slab x{world}, RCCL, halo={halo}"},
-        "global_iters_per_sec": round(its, 2),
-        "hbm_gbps": round(88.0 * U * its / 1e9, 1),
-        "hbm_gbps_convention": "88 B per unknown per iteration (SURVEY 8d), summed over GPUs; the default REL_2NORM path really moves 60 B",
-        "moved_gbps_per_gpu": round((60.0 if rule == _capi.RULE_REL_2NORM else 64.0) * U * its / 1e9 / world, 1),
-    }
-    # whole-iteration roofline per GPU (kernels + collectives + driver); the per-kernel figures are in the 1-GPU bench line
-    moved = out["moved_gbps_per_gpu"]
-    out["roofline"] = {"bound": "hbm", "achieved": moved, "peak": 8000.0, "unit": "GB/s", "frac": round(moved / 8000.0, 4),
-                       "traffic": None, "scope": "bytes one GPU has to move per iteration / wall time per iteration, collectives included"}
-    dist.barrier()
-    if os.environ.get("WORLD_SIZE") is not None and "TORCHELASTIC_RUN_ID" not in os.environ and world == 1:
-        dist.destroy_process_group()                          # started without a launcher: leave nothing behind
-    return out

@@ -224,6 +224,8 @@ class MatrixFreeSolver:
         """inner_eps only matters for a MatrixFreeSystem created with dtype=F32_MIXED (config 3)."""
         h = self.system._handle
         h.set_rhs(self.b)
+        if true_solution is not None and len(true_solution) > 0:
+            h.set_true_solution(true_solution)                   # matrix_free_system.cpp:451-455 uses the caller's vector
         p = default_params(_capi.RULE_REL_2NORM)
         p.eps_rel, p.max_iterations = self.eps, self.maxIterations
         p.diagnostics = 1 if self.iteration_callback else 0
@@ -279,8 +281,8 @@ class MSGSolver:
         self._stop.value = 0                                     # msg_solver.cpp:12-13
         h = self.a._handle
         h.set_rhs(self.b)
-        if isinstance(self.a, CrsMatrix) and true_solution is not None and len(true_solution) > 0:
-            h.set_true_solution(true_solution)                   # a generic matrix has no built-in exact solution
+        if true_solution is not None and len(true_solution) > 0:
+            h.set_true_solution(true_solution)                   # the error norms use the vector that was passed in (msg_solver.cpp:64-72,132-139)
         p = default_params(_capi.RULE_MSG_MAXNORM)
         p.max_iterations = self.maxIterations
         p.eps_precision, p.eps_residual, p.eps_exact_error = self.eps_precision, self.eps_residual, self.eps_exact_error

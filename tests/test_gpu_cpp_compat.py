@@ -10,13 +10,18 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "compat_driver.cpp")
 EXE = os.path.join(ROOT, "tests", "cpp", "compat_driver")
+HEADERS = [os.path.join(ROOT, "iterative_solvers_amd", "compat", "mi355cg_compat.hpp"), os.path.join(ROOT, "include", "mi355cg.h")]
+
+
+def _stale(exe, src):
+    """The binaries embed struct layouts of the C ABI: rebuild when a header is newer, not only the source."""
+    return not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(f) for f in [src] + HEADERS)
 
 
 def build_driver():
     from iterative_solvers_amd import build as b
     b.build()
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(SRC), os.path.getmtime(
-            os.path.join(ROOT, "iterative_solvers_amd", "compat", "mi355cg_compat.hpp"))):
+    if _stale(EXE, SRC):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror",
                                "-I", os.path.join(ROOT, "iterative_solvers_amd", "compat"), SRC,
                                "-L", os.path.join(ROOT, "iterative_solvers_amd"), "-lmi355cg",
@@ -94,7 +99,7 @@ def _build_cli():
     b.build()
     src = os.path.join(ROOT, "iterative_solvers_amd", "cli", "solver_main.cpp")
     exe = os.path.join(ROOT, "iterative_solvers_amd", "cli", "solver_cli")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    if _stale(exe, src):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I",
                                os.path.join(ROOT, "iterative_solvers_amd", "compat"), src, "-L",
                                os.path.join(ROOT, "iterative_solvers_amd"), "-lmi355cg",

@@ -138,7 +138,8 @@ def test_bench_distributed_leg_runs_under_torchrun_with_rccl():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["steps"] == 60 and j["value"] > 0 and j["scaling"] == "weak"
-    assert "halo=gather" in j["config"]["parallelism"]
+    assert "native RCCL team" in j["config"]["parallelism"] and "note" not in j          # the native loop ran, not the fallback
+    assert j["phases_ms"]["kernels_ms"] > 0 and j["phases_ms"]["wall_ms"] > 0
 
 
 def test_slab_handles_refuse_the_whole_grid_entry_points():

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""In-process sweep of the launch-geometry knobs (env vars read at mi355cg_create).
-Usage: python tools/tune.py [N] [iters]"""
-import itertools
+"""In-process sweep of the launch-geometry knobs (env vars read at mi355cg_create): item height, waves, rows in flight.
+Usage: python tools/tune.py N iters [f32] -- "K=V K=V" "K=V" ...      (each quoted group is one configuration; "" = defaults)
+Prints iterations/s and, per launch kind, the mean in-loop duration (HIP events) and the bandwidth its compulsory
+bytes correspond to (stencil 3 words; update 3 words on odd / 6 on even iterations = 4.5 on average)."""
 import os
 import sys
 import time
@@ -11,15 +12,24 @@ sys.path.insert(0, ROOT)
 import iterative_solvers_amd as isa
 from iterative_solvers_amd import _capi
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+args = sys.argv[1:]
+cfgs = args[args.index("--") + 1:] if "--" in args else [""]
+pos = args[:args.index("--")] if "--" in args else args
+N = int(pos[0]) if pos else 4096
+ITERS = int(pos[1]) if len(pos) > 1 else 400
+F32 = len(pos) > 2 and pos[2] == "f32"
 U = (N // 2 - 1) * (3 * N // 2 - 1)
+WB = 4 if F32 else 8
+KNOBS = ("MI355CG_ITEM_ROWS", "MI355CG_WAVES", "MI355CG_BLOCKS", "MI355CG_DEPTH", "MI355CG_GRAPH")
 
 
-def measure(env):
-    for k, v in env.items():
-        os.environ[k] = str(v)
-    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+def measure(cfg):
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    for kv in cfg.split():
+        k, v = kv.split("=")
+        os.environ[k] = v
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED if F32 else isa.F64)
     h = s._handle
     p = isa.default_params(_capi.RULE_REL_2NORM)
     p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = ITERS, 1, 0, 0, 500
@@ -32,24 +42,8 @@ def measure(env):
     return ITERS / dt, ts, tu, lay
 
 
-def run(env):
-    its, ts, tu, lay = measure(env)
-    xf = os.environ.get('MI355CG_XFUSE', '1') != '0'
-    ws, wu = (48, 24) if xf else (32, 48)
-    print(f"{env} its/s={its:8.1f} GB/s(88B)={88*U*its/1e9:7.1f} stencil={ts*1e3:7.1f}us ({ws*U/ts/1e6:6.0f} GB/s) "
-          f"update={tu*1e3:7.1f}us ({wu*U/tu/1e6:6.0f} GB/s) grid={lay['grid_stencil']}/{lay['grid_update']} ty={lay['rows_per_item']}", flush=True)
-
-
-def ab(configs, rounds=5):
-    """Interleaved rounds in one process (the boxes drift by several % within seconds): median and best per config."""
-    res = {i: [] for i in range(len(configs))}
-    for _ in range(rounds):
-        for i, env in enumerate(configs):
-            res[i].append(measure(env)[0])
-    for i, env in enumerate(configs):
-        v = sorted(res[i])
-        print(f"{env} median {v[len(v)//2]:8.1f} it/s   best {v[-1]:8.1f}   worst {v[0]:8.1f}", flush=True)
-
-
-if __name__ == "__main__":
-    ab([{"MI355CG_MAX_ROWS": 24}, {"MI355CG_MAX_ROWS": 16}, {"MI355CG_MAX_ROWS": 32}, {"MI355CG_MAX_ROWS": 48}, {"MI355CG_MAX_ROWS": 512}], rounds=3)
+for rep in range(2):
+    for cfg in cfgs:
+        its, ts, tu, lay = measure(cfg)
+        print(f"N={N} {'f32' if F32 else 'f64'} [{cfg:40s}] {its:8.1f} it/s = {7.5*WB*U*its/1e9:6.0f} GB/s moved | stencil {ts*1e3:8.1f} us ({3*WB*U/ts/1e6:5.0f} GB/s) "
+              f"update {tu*1e3:8.1f} us ({4.5*WB*U/tu/1e6:5.0f} GB/s) grid={lay['grid_stencil']} ty={lay['rows_per_item']}", flush=True)
