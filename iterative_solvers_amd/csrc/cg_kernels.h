@@ -266,6 +266,70 @@ __device__ inline Decision reduce_and_decide(const StateLite& s, const RuleParam
     }
     return decide_after_update(s, rp, rr, rmax, dmax, emax, d2, e2);
 }
+// ---- a part's record, written by the LAST block of the last launch of a phase (teams, csrc/team.h) ------------------
+// Record = the part's partials reduced in slot order (sums as hi/lo pairs, then the maxes) + its stop request: what
+// crosses parts after each phase.  Producing it in the producer launch itself (arrival ticket, last arriver reduces)
+// instead of a separate one-block launch takes a launch boundary and a kernel off the critical path
+// producer -> record -> all-gather -> consumer.
+constexpr int kRecWords = 16;                     // doubles per record
+constexpr int kRecStopWord = 9;                   // word that carries a rank's stop request (max over ranks = stop everywhere)
+constexpr int kMaxRecDst = 16;
+struct RecSpec {
+    int enabled;                                  // 0: this launch does not end a phase of a team
+    int nslots;                                   // partial slots of the whole phase (interior + edge launches)
+    unsigned* ticket;                             // arrival counter, 0 between launches
+    const int* stop_req;                          // pinned host word (update phase), may be null
+    int ndst;
+    double* const* dst;                           // DEVICE array: this part's slot in the gathered buffer of every part this process drives
+                                                  // (an array inside the by-value kernel arguments would be spilled as soon as it is indexed at run time)
+};
+// A block's partial: a plain store, or -- when another block of the SAME launch will read it (team record) -- a
+// write-through store at agent scope (cdna_hip_programming.md Guideline 16, R1: sc1 payload, drain, ticket; NO release
+// fence: on this 8-XCD part an agent-scope release writes back the whole dirty L2, i.e. the launch's own output stream,
+// once per block -- measured 2x on the launch).
+__device__ inline void store_partial(double* p, double v, bool publish) {
+    if (publish) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+// which: 0 = stencil partials (FA_*), 1 = update partials (FB_*).  Called by all threads of one block.
+__device__ inline void emit_record(int which, const double* part, int stride, const RecSpec& rs, double* lds) {
+    __shared__ double rec[kRecWords];
+    if (threadIdx.x < kRecWords) rec[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int nsum = which == 0 ? kNumSumsA : kNumSumsB, lo_off = which == 0 ? FA_LO : FB_LO;
+    for (int f = 0; f < nsum; ++f) {
+        const dd t = reduce_parts_dd(part + f * stride, part + (f + lo_off) * stride, rs.nslots, 1, lds);
+        if (threadIdx.x == 0) { rec[f] = t.hi; rec[f + lo_off] = t.lo; }
+    }
+    if (which == 1) {
+        for (int f = FB_RMAX; f < FB_RMAX + 3; ++f) {
+            const double t = reduce_parts<true>(part + f * stride, rs.nslots, 1, lds);
+            if (threadIdx.x == 0) rec[f] = t;
+        }
+        if (threadIdx.x == 0 && rs.stop_req) rec[kRecStopWord] = *(const volatile int*)rs.stop_req ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // the destinations may be another GPU's memory (LOCAL team over peer access): system-scope write-through stores
+    for (int i = threadIdx.x; i < rs.ndst * kRecWords; i += kBlock)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rs.dst[i / kRecWords] + i % kRecWords),
+                           __builtin_bit_cast(unsigned long long, rec[i % kRecWords]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Epilogue of a producer launch; thread 0 has just stored this block's partials with store_partial(..., true).
+// Returns after the last block emitted the record.
+__device__ inline void arrive_and_record(int which, const double* part, int stride, const RecSpec& rs, double* lds) {
+    if (!rs.enabled) return;
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-through partials have landed before the ticket
+        last = __hip_atomic_fetch_add(rs.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // drop this CU's / XCD's stale lines once, then plain loads
+    emit_record(which, part, stride, rs, lds);
+    if (threadIdx.x == 0) __hip_atomic_store(rs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- phase A': fused direction update + 5-point stencil + dots ------------------------------------
 template <typename T>
 struct StencilArgs {
@@ -283,6 +347,7 @@ struct StencilArgs {
     int want_diag;
     int store_ghosts;    // part of a decomposed grid: also store p_new of the ghost rows (recomputed from the local ghost copies
                          // of r and p_old, bit-identical to the neighbour's rows), so the direction never has to cross ranks
+    RecSpec rec;         // team: this launch ends the stencil phase -> its last block writes the part's record
 };
 
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
@@ -560,9 +625,11 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     if (MSG) tz = block_reduce_dd(acc_rz, lds);
     if (threadIdx.x == 0 && a.partA) {
         const int b = a.slotA + blockIdx.x, st = a.strideA;
-        a.partA[FA_PAP * st + b] = tp.hi; a.partA[(FA_PAP + FA_LO) * st + b] = tp.lo;
-        a.partA[FA_RZ * st + b] = tz.hi;  a.partA[(FA_RZ + FA_LO) * st + b] = tz.lo;
+        const bool pub = FUSED && a.rec.enabled;
+        store_partial(a.partA + FA_PAP * st + b, tp.hi, pub); store_partial(a.partA + (FA_PAP + FA_LO) * st + b, tp.lo, pub);
+        store_partial(a.partA + FA_RZ * st + b, tz.hi, pub);  store_partial(a.partA + (FA_RZ + FA_LO) * st + b, tz.lo, pub);
     }
+    if (FUSED) arrive_and_record(0, a.partA, a.strideA, a.rec, lds);
 }
 
 // ---- flat update: state initialisation, resume step of the mixed-precision path, generic CSR path -----------------
@@ -702,6 +769,7 @@ struct UpdateStArgs {
     const CgState* s_in; CgState* s_out;
     int rule;
     int reverse;         // take the items from the last to the first (start where the stencil launch ended)
+    RecSpec rec;         // team: this launch ends the update phase -> its last block writes the part's record
 };
 
 template <typename T, int VEC, int XM, bool HAS_U, int DEPTH, bool DESC>
@@ -869,16 +937,19 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     if (FULL && HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce_dd(s_e2, lds); }
     if (threadIdx.x == 0) {
         const int b = a.slotB + blockIdx.x, st = a.strideB;
-        a.partB[FB_RR * st + b] = t_rr.hi; a.partB[(FB_RR + FB_LO) * st + b] = t_rr.lo;
-        a.partB[FB_D2 * st + b] = t_d2.hi; a.partB[(FB_D2 + FB_LO) * st + b] = t_d2.lo;
-        a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
-        a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
+        const bool pub = a.rec.enabled != 0;
+        store_partial(a.partB + FB_RR * st + b, t_rr.hi, pub); store_partial(a.partB + (FB_RR + FB_LO) * st + b, t_rr.lo, pub);
+        store_partial(a.partB + FB_D2 * st + b, t_d2.hi, pub); store_partial(a.partB + (FB_D2 + FB_LO) * st + b, t_d2.lo, pub);
+        store_partial(a.partB + FB_E2 * st + b, t_e2.hi, pub); store_partial(a.partB + (FB_E2 + FB_LO) * st + b, t_e2.lo, pub);
+        store_partial(a.partB + FB_RMAX * st + b, t_rmax, pub); store_partial(a.partB + FB_DMAX * st + b, t_dmax, pub);
+        store_partial(a.partB + FB_EMAX * st + b, t_emax, pub);
         if (blockIdx.x == 0) {
             copy_state(a.s_out, a.s_in);
             CgState* o = a.s_out;
             o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz;
         }
     }
+    arrive_and_record(1, a.partB, a.strideB, a.rec, lds);
 }
 
 // ---- end-of-chunk check: same decision as the next stencil prologue, without advancing -------------

@@ -43,7 +43,7 @@ int env_int(const char* name, int dflt) {
 
 inline long long round_up(long long v, long long m) { return (v + m - 1) / m * m; }
 
-constexpr int kRecHeader = 16;     // doubles reserved for the sums (hi/lo pairs) and maxes at the head of a part's record
+constexpr int kRecHeader = kRecWords;     // doubles reserved for the sums (hi/lo pairs) and maxes at the head of a part's record
 constexpr int kStripCols = 128;    // fp64 strip = 64 lanes x double2: the unit of the x-cuts of a 2-D decomposition
 
 struct EventPool {
@@ -90,6 +90,7 @@ struct mi355cg_ctx {
     mi355cg_params dist_prm{};                    // slab mode: parameters given to mi355cg_dist_begin
     bool dist_active = false, is_slab = false;
     CgState *sA = nullptr, *sB = nullptr, *summary = nullptr;
+    unsigned* ticket = nullptr;         // arrival counter of the launch that writes a team record (RecSpec)
     HistEntry* hist = nullptr;
     CgState* summary_h = nullptr;       // pinned
     HistEntry* hist_h = nullptr;        // pinned
@@ -304,7 +305,7 @@ struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool x2 = false; };
 
 // Phase A'.  Does NOT flip c->cur (a part's interior and edge launches share one direction pair).
 template <typename T, int VEC>
-void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], const Where& w, const PartSrc& pb) {
+void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], const Where& w, const PartSrc& pb, const RecSpec* rec = nullptr) {
     if (w.plan->wl.nitems == 0) return;
     StencilArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
@@ -313,6 +314,7 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
     a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slot;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     a.store_ghosts = c->is_slab ? 1 : 0;
+    if (rec) a.rec = *rec;
     const dim3 grid(w.plan->grid), block(kBlock);
     const bool msg = cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM, gc = c->has_gc, d3 = c->depth == 3;
 #define MI355CG_ST(MSG, D, GC) hipLaunchKernelGGL((k_stencil<T, VEC, true, MSG, D, true, GC>), grid, block, 0, w.stream, a)
@@ -328,7 +330,7 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
 // Phase B on the stencil's work items, marched the other way (it starts on what the stencil launch touched last).
 // c->cur was flipped after this iteration's stencil launch: it is the iteration number's parity.
 template <typename T, int VEC>
-void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* const p[2], const T* u, const Where& w, const PartSrc& pa) {
+void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* const p[2], const T* u, const Where& w, const PartSrc& pa, const RecSpec* rec = nullptr) {
     if (w.plan->wl.nitems == 0) return;
     UpdateStArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
@@ -336,6 +338,7 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
     a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
     a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slot;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
+    if (rec) a.rec = *rec;
     const dim3 grid(w.plan->grid), block(kBlock);
     const bool d3 = c->depth == 3;
 #define MI355CG_UST(XM, HASU) do { if (d3) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 3, true>), grid, block, 0, w.stream, a); \
@@ -775,6 +778,7 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     }
     hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
     hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
+    if (hipMalloc((void**)&c->ticket, sizeof(unsigned)) != hipSuccess || hipMemset(c->ticket, 0, sizeof(unsigned)) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "ticket allocation failed"); return cleanup(); }
     // The zero-fills above run on the NULL stream and are asynchronous to the host; the context's own stream is
     // non-blocking and does not order with them.  Without this wait a delayed memset can land AFTER the first upload
     // or kernel of the context and wipe it (seen as a right-hand side of zeros -> "converged" at iteration 0).
@@ -875,7 +879,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf, c->pf[0], c->pf[1], c->apf,
-                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
+                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist, c->ticket};
     for (void* p : dev) if (p) hipFree(p);
     if (c->csr_row_map) hipFree(c->csr_row_map);
     if (c->csr_entries) hipFree(c->csr_entries);

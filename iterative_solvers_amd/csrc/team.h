@@ -8,10 +8,12 @@
 //     crosses parts: the fused stencil launch recomputes it on its halo from the ghost copies of r and the old direction and
 //     keeps the result in its ghost rows and ghost columns.)
 // Transports:
-//   RCCL   one process per GPU.  The library owns its communicator (mi355cg_team_unique_id -> ncclCommInitRank); RCCL is
+//   RCCL   one process per GPU.  The library owns its communicators (mi355cg_team_unique_id -> ncclCommInitRank); RCCL is
 //          resolved at run time from the librccl already in the process (torch's) or from the ROCm installation.
-//          ncclAllGather of the records and one ncclSend/ncclRecv group per iteration for the halo, all on a SECOND
-//          stream; events order it with the compute stream, the host never blocks inside an iteration.
+//          The records: ncclAllGather issued on the COMPUTE stream, between producer and consumer launch (nothing else
+//          could run there: both launches of an iteration need all records).  The halo: one ncclSend/ncclRecv group per
+//          iteration on a SECOND stream and a second communicator, ordered with the compute stream by two events, so it
+//          overlaps the interior launches.  The host never blocks inside an iteration.
 //   LOCAL  one process drives all parts, on one or several GPUs: records are written straight into every part's gathered
 //          buffer, halo segments are device-to-device copies.  This is what a single-process host (the reference's
 //          DirichletSolver is one) uses, and what lets one GPU rehearse an 8-part run bit for bit.
@@ -113,6 +115,7 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -129,7 +132,7 @@ RcclApi* rccl_api() {
     if (!h) return nullptr;
 #define MI355CG_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name)); if (!api.field) return nullptr
     MI355CG_SYM(GetUniqueId, "ncclGetUniqueId"); MI355CG_SYM(CommInitRank, "ncclCommInitRank"); MI355CG_SYM(CommDestroy, "ncclCommDestroy");
-    MI355CG_SYM(AllGather, "ncclAllGather"); MI355CG_SYM(Send, "ncclSend"); MI355CG_SYM(Recv, "ncclRecv");
+    MI355CG_SYM(AllGather, "ncclAllGather"); MI355CG_SYM(Send, "ncclSend"); MI355CG_SYM(Recv, "ncclRecv"); MI355CG_SYM(Broadcast, "ncclBroadcast");
     MI355CG_SYM(GroupStart, "ncclGroupStart"); MI355CG_SYM(GroupEnd, "ncclGroupEnd"); MI355CG_SYM(GetErrorString, "ncclGetErrorString");
 #undef MI355CG_SYM
     api.lib = h;
@@ -143,8 +146,8 @@ RcclApi* rccl_api() {
     } while (0)
 
 // ---- small kernels of the team loop ------------------------------------------------------------------------------
-constexpr int kMaxLocalParts = 16;
-constexpr int kRecStop = 9;                       // record word that carries a rank's stop request (max over ranks = stop everywhere)
+constexpr int kMaxLocalParts = kMaxRecDst;
+constexpr int kRecStop = kRecStopWord;
 struct TeamRecArgs {
     const double* part; int n, stride;
     int nsum, lo_off, max_first, nmax;            // as RecordArgs
@@ -198,6 +201,7 @@ struct TeamPart {
     hipStream_t comm = nullptr;
     double *gA = nullptr, *gB = nullptr;                  // gathered records [world][kRecHeader]
     double *send_cols = nullptr, *recv_cols = nullptr;    // packed column messages
+    double **dstA = nullptr, **dstB = nullptr;            // device arrays: where this part's records go (one slot per local part)
     std::vector<Seg> sends, recvs;                        // ordered by (peer, id)
     std::vector<long long> send_off, recv_off;            // column messages: offset in send_cols / recv_cols
     ColArgs pack{}, unpack{};
@@ -215,7 +219,8 @@ struct mi355cg_team_s {
     std::vector<Seg> segs;
     std::vector<TeamPart> parts;            // the parts this process drives (all of them: LOCAL; one: RCCL)
     bool rccl = false;
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;              // records: ncclAllGather issued on the COMPUTE stream (no cross-stream hop on the critical path)
+    ncclComm_t comm_halo = nullptr;         // halo messages on the comm stream; its own communicator, so the two streams never serialise on one
     hipStream_t hub = nullptr;              // LOCAL: joins the parts' record events
     hipEvent_t ev_hub = nullptr;
     int* stop_h = nullptr;                  // pinned: this process's stop request, read by k_team_record
@@ -233,10 +238,11 @@ void team_free(mi355cg_team_s* t) {
         if (p.c && p.c->stream) hipStreamSynchronize(p.c->stream);
         if (p.comm) { hipStreamSynchronize(p.comm); }
     }
+    if (t->comm_halo && rccl_api()) rccl_api()->CommDestroy(t->comm_halo);
     if (t->comm && rccl_api()) rccl_api()->CommDestroy(t->comm);
     for (auto& p : t->parts) {
         if (p.c) hipSetDevice(p.c->device);
-        for (void* q : {(void*)p.gA, (void*)p.gB, (void*)p.send_cols, (void*)p.recv_cols}) if (q) hipFree(q);
+        for (void* q : {(void*)p.gA, (void*)p.gB, (void*)p.send_cols, (void*)p.recv_cols, (void*)p.dstA, (void*)p.dstB}) if (q) hipFree(q);
         for (hipEvent_t e : {p.ev_recA, p.ev_gA, p.ev_redge, p.ev_recB, p.ev_gB, p.ev_halo}) if (e) hipEventDestroy(e);
         if (p.comm) hipStreamDestroy(p.comm);
         if (p.c) mi355cg_destroy(p.c);
@@ -272,6 +278,15 @@ int team_finish_setup(mi355cg_team_s* t) {
         p.pack.buf = p.send_cols; p.unpack.buf = p.recv_cols;
         HIPCK(hipDeviceSynchronize());
     }
+    for (auto& p : t->parts) {                                     // every part's record goes to every local part's gathered buffer
+        HIPCK(hipSetDevice(p.c->device));
+        std::vector<double*> da, db;
+        for (auto& q : t->parts) { da.push_back(q.gA + (size_t)p.rank * kRecHeader); db.push_back(q.gB + (size_t)p.rank * kRecHeader); }
+        HIPCK(hipMalloc((void**)&p.dstA, sizeof(double*) * da.size()));
+        HIPCK(hipMalloc((void**)&p.dstB, sizeof(double*) * db.size()));
+        HIPCK(hipMemcpy(p.dstA, da.data(), sizeof(double*) * da.size(), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(p.dstB, db.data(), sizeof(double*) * db.size(), hipMemcpyHostToDevice));
+    }
     if (!t->rccl) {
         t->hub_device = t->parts[0].c->device;
         HIPCK(hipSetDevice(t->hub_device));
@@ -298,17 +313,14 @@ double* seg_ptr(const mi355cg_ctx* c, double* v, const Seg& s) { return v + (row
 // all-gather of the records of phase `which` (0 = A, 1 = B): after it every part's compute stream may read its gathered buffer
 int team_exchange_records(mi355cg_team_s* t, int which) {
     if (t->rccl) {
+        // in-stream: the compute stream itself carries the all-gather between the record kernel and the consumer launch
         TeamPart& p = t->parts[0];
         double* g = which == 0 ? p.gA : p.gB;
-        HIPCK(hipStreamWaitEvent(p.comm, which == 0 ? p.ev_recA : p.ev_recB, 0));
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.comm); }
+        if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.c->stream); }
         if (t->world > 1 || env_int("MI355CG_FORCE_COLLECTIVES", 0))
-            NCCLCK(rccl_api()->AllGather(g + (size_t)p.rank * kRecHeader, g, kRecHeader, ncclDouble, t->comm, p.comm));     // in place
-        if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.comm); p.comm_pairs.push_back({e0, e1}); } }
-        hipEvent_t done = which == 0 ? p.ev_gA : p.ev_gB;
-        HIPCK(hipEventRecord(done, p.comm));
-        HIPCK(hipStreamWaitEvent(p.c->stream, done, 0));
+            NCCLCK(rccl_api()->AllGather(g + (size_t)p.rank * kRecHeader, g, kRecHeader, ncclDouble, t->comm, p.c->stream));     // in place
+        if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.c->stream); p.comm_pairs.push_back({e0, e1}); } }
         return MI355CG_OK;
     }
     if (t->parts.size() == 1) return MI355CG_OK;                   // same stream wrote the record
@@ -330,12 +342,12 @@ int team_exchange_halo(mi355cg_team_s* t) {
             for (size_t i = 0; i < p.sends.size(); ++i) {
                 const Seg& s = p.sends[i];
                 const double* src = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.send_cols + p.send_off[i];
-                NCCLCK(rccl_api()->Send(src, (size_t)seg_count(s), ncclDouble, s.dst, t->comm, p.comm));
+                NCCLCK(rccl_api()->Send(src, (size_t)seg_count(s), ncclDouble, s.dst, t->comm_halo, p.comm));
             }
             for (size_t i = 0; i < p.recvs.size(); ++i) {
                 const Seg& s = p.recvs[i];
                 double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
-                NCCLCK(rccl_api()->Recv(dst, (size_t)seg_count(s), ncclDouble, s.src, t->comm, p.comm));
+                NCCLCK(rccl_api()->Recv(dst, (size_t)seg_count(s), ncclDouble, s.src, t->comm_halo, p.comm));
             }
             NCCLCK(rccl_api()->GroupEnd());
             if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, p.comm, a); }
@@ -367,6 +379,15 @@ int team_exchange_halo(mi355cg_team_s* t) {
     return MI355CG_OK;
 }
 
+// the record a producer launch writes itself when it ends a phase (cg_kernels.h: arrive_and_record)
+RecSpec team_rec_spec(mi355cg_team_s* t, TeamPart& p, int which, int nslots) {
+    RecSpec rs{};
+    rs.enabled = 1; rs.nslots = nslots; rs.ticket = p.c->ticket; rs.stop_req = which == 1 ? t->stop_h : nullptr;
+    rs.ndst = (int)t->parts.size(); rs.dst = which == 0 ? p.dstA : p.dstB;
+    return rs;
+}
+
+// the same record from a separate one-block launch (after the initialisation pass)
 void team_record(mi355cg_team_s* t, TeamPart& p, int which, int nslots) {
     mi355cg_ctx* c = p.c;
     TeamRecArgs a{};
@@ -376,7 +397,7 @@ void team_record(mi355cg_team_s* t, TeamPart& p, int which, int nslots) {
     a.ndst = 0;
     for (auto& q : t->parts) a.dst[a.ndst++] = (which == 0 ? q.gA : q.gB) + (size_t)p.rank * kRecHeader;
     hipLaunchKernelGGL(k_team_record, dim3(1), dim3(kBlock), 0, c->stream, a);
-    hipEventRecord(which == 0 ? p.ev_recA : p.ev_recB, c->stream);
+    if (!t->rccl) hipEventRecord(which == 0 ? p.ev_recA : p.ev_recB, c->stream);
 }
 
 int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
@@ -451,22 +472,26 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         if (first_chunk || want_stop) { m = 1; first_chunk = false; }
         if (m <= 0) m = 1;
         for (int k = 0; k < m; ++k) {
-            // ---- stencil phase ----
+            // ---- stencil phase: the launch that ends it writes the part's record (its last block) ----
             for (auto& p : t->parts) {
                 mi355cg_ctx* c = p.c;
                 HIPCK(hipSetDevice(c->device));
                 hipEvent_t e0 = nullptr;
                 prof_begin(c, &e0);
                 if (p.split) {
+                    const RecSpec rs = team_rec_spec(t, p, 0, c->interior.grid + c->edge.grid);
                     launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, gsrc(p, 1));
                     prof_end(c, 0, e0);
                     HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
                     prof_begin(c, &e0);
-                    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, gsrc(p, 1));
-                } else launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), gsrc(p, 1));
+                    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, gsrc(p, 1), &rs);
+                } else {
+                    const RecSpec rs = team_rec_spec(t, p, 0, c->whole.grid);
+                    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), gsrc(p, 1), &rs);
+                }
                 prof_end(c, 0, e0);
                 c->cur ^= 1;
-                team_record(t, p, 0, p.split ? c->interior.grid + c->edge.grid : c->whole.grid);
+                if (!t->rccl) HIPCK(hipEventRecord(p.ev_recA, c->stream));
             }
             if (int rc = team_exchange_records(t, 0)) return rc;
             // ---- update phase: edge items first, so the halo of r is on its way while the interior is updated ----
@@ -476,18 +501,21 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
                 hipEvent_t e0 = nullptr;
                 prof_begin(c, &e0);
                 if (p.split) {
-                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, gsrc(p, 0));
+                    const RecSpec rs = team_rec_spec(t, p, 1, c->interior.grid + c->edge.grid);
+                    const bool has_int = c->interior.wl.nitems > 0;
+                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, gsrc(p, 0), has_int ? nullptr : &rs);
                     if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
                     prof_end(c, 1, e0);
                     HIPCK(hipEventRecord(p.ev_redge, c->stream));
                     prof_begin(c, &e0);
-                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, gsrc(p, 0));
+                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, gsrc(p, 0), &rs);
                 } else {
-                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), gsrc(p, 0));
+                    const RecSpec rs = team_rec_spec(t, p, 1, c->whole.grid);
+                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), gsrc(p, 0), &rs);
                     HIPCK(hipEventRecord(p.ev_redge, c->stream));
                 }
                 prof_end(c, 1, e0);
-                team_record(t, p, 1, p.split ? c->interior.grid + c->edge.grid : c->whole.grid);
+                if (!t->rccl) HIPCK(hipEventRecord(p.ev_recB, c->stream));
                 HIPCK(hipGetLastError());
             }
             if (int rc = team_exchange_halo(t)) return rc;
@@ -647,6 +675,22 @@ int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double
     if (hipSetDevice(device) != hipSuccess) { team_free(t); return fail(MI355CG_ERR_HIP, "hipSetDevice(%d) failed", device); }
     const ncclResult_t nr = api->CommInitRank(&t->comm, world, id, rank);
     if (nr != ncclSuccess) { t->comm = nullptr; team_free(t); return fail(MI355CG_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(nr)); }
+    if (world > 1) {
+        // second communicator for the halo messages: its id comes from rank 0 through the first one
+        ncclUniqueId id2;
+        unsigned char* dbuf = nullptr;
+        auto bail = [&](const char* what, const char* why) { if (dbuf) hipFree(dbuf); team_free(t); return fail(MI355CG_ERR_HIP, "%s failed: %s", what, why); };
+        if (rank == 0) { const ncclResult_t r0 = api->GetUniqueId(&id2); if (r0 != ncclSuccess) return bail("ncclGetUniqueId", api->GetErrorString(r0)); }
+        if (hipMalloc((void**)&dbuf, sizeof id2) != hipSuccess) return bail("hipMalloc", "id buffer");
+        if (rank == 0 && hipMemcpy(dbuf, &id2, sizeof id2, hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy", "id upload");
+        hipStream_t st = t->parts[0].comm;
+        const ncclResult_t rb = api->Broadcast(dbuf, dbuf, sizeof id2, ncclUint8, 0, t->comm, st);
+        if (rb != ncclSuccess) return bail("ncclBroadcast", api->GetErrorString(rb));
+        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&id2, dbuf, sizeof id2, hipMemcpyDeviceToHost) != hipSuccess) return bail("hipMemcpy", "id download");
+        hipFree(dbuf); dbuf = nullptr;
+        const ncclResult_t n2 = api->CommInitRank(&t->comm_halo, world, id2, rank);
+        if (n2 != ncclSuccess) { t->comm_halo = nullptr; return bail("ncclCommInitRank (halo communicator)", api->GetErrorString(n2)); }
+    }
     *out = t;
     return MI355CG_OK;
 }
