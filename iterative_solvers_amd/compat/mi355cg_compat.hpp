@@ -256,6 +256,7 @@ class MSGSolver : public Solver {
     std::function<void(int, double, double, double)> iteration_callback;     // shadows the base member, as in the reference
     std::atomic<int> stop_requested{0};
     bool verbose = true;
+    int poll_interval = 0;
 public:
     MSGSolver(const KokkosCrsMatrix& a_, const KokkosVector& b_, double eps_ = 1e-6, int maxIterations_ = 10000)
         : Solver(a_, b_, eps_, maxIterations_, "Метод серединных градиентов"),
@@ -269,6 +270,10 @@ public:
     void resetStop() { stop_requested = 0; }
     bool isStopRequested() const { return stop_requested != 0; }
     void setVerbose(bool v) { verbose = v; }              // the reference always prints (msg_solver.cpp:172-177,202-208)
+    // Iterations queued on the GPU between two looks at the stop flag (and two deliveries of callbacks).  The reference
+    // looks every iteration (msg_solver.cpp:82-87); here the default is the callback cadence (100), 1 is allowed and
+    // costs one host round trip per iteration.  The first iteration of a solve is always on its own.
+    void setPollInterval(int iterations) { poll_interval = iterations > 0 ? iterations : 0; }
     std::string getStopReasonText() const {
         switch (stop_reason) {
             case StopCriterion::ITERATIONS: return "Достигнуто максимальное число итераций";
@@ -298,6 +303,7 @@ public:
         p.max_iterations = maxIterations;
         p.eps_precision = eps_precision; p.eps_residual = eps_residual; p.eps_exact_error = eps_exact_error;
         p.use_true_solution = true_solution.extent(0) > 0 ? 1 : 0;
+        p.sync_every = poll_interval;
         p.callback_every = 100;
         std::function<void(int, double, double, double)> cb = [this](int it, double pr, double rs, double er) {
             // progress print of msg_solver.cpp:172-177 (cosmetic; a solve that converges exactly on a
@@ -563,12 +569,14 @@ public:
     void setIterationCallback(std::function<void(int, double, double, double)> cb) { iteration_callback = std::move(cb); }
     void setCompletionCallback(std::function<void(const SolverResults&)> cb) { completion_callback = std::move(cb); }
     void setVerbose(bool v) { verbose_ = v; }
+    void setPollInterval(int iterations) { poll_interval_ = iterations; }         // see MSGSolver::setPollInterval
 
     SolverResults solve() {                                                       // dirichlet_solver.cpp:61-131
         if (!grid) throw std::runtime_error("Сетка не инициализирована");
         solver = std::make_unique<MSGSolver>(grid->get_matrix(), grid->get_rhs(),
                                              std::min({eps_precision, eps_residual, eps_exact_error}), max_iterations);
         solver->setVerbose(verbose_);
+        solver->setPollInterval(poll_interval_);
         solver->setPrecisionEps(use_precision_stopping ? eps_precision : -1.0);
         solver->setResidualEps(use_residual_stopping ? eps_residual : -1.0);
         solver->setExactErrorEps(use_error_stopping ? eps_exact_error : -1.0);
@@ -617,4 +625,5 @@ public:
 private:
     SolverResults last_;
     bool verbose_ = true;
+    int poll_interval_ = 0;
 };

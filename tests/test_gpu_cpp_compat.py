@@ -125,3 +125,37 @@ def test_console_driver_config1_plumbing():
     assert out.returncode == 0 and "итераций: 701," in out.stdout            # the reference's own count
     out = subprocess.run([exe, "--n", "7"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "rejected" in out.stderr
+
+
+def _build_worker():
+    from iterative_solvers_amd import build as b
+    b.build()
+    src = os.path.join(ROOT, "tests", "cpp", "worker_driver.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "worker_driver")
+    if _stale(exe, src):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread",
+                               "-I", os.path.join(ROOT, "iterative_solvers_amd", "compat"), src,
+                               "-L", os.path.join(ROOT, "iterative_solvers_amd"), "-lmi355cg",
+                               "-Wl,-rpath," + os.path.join(ROOT, "iterative_solvers_amd"), "-o", exe])
+    return exe
+
+
+def test_worker_driver_compiles():
+    assert os.path.exists(_build_worker())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("poll", [0, 1, 10])
+def test_solver_worker_thread_and_stop_from_the_gui_thread(poll):
+    """SURVEY 8f row f4, qt_gui/src/mainwindow.cpp:46-68,234-258: solve() on a worker thread, requestStop() from another
+    thread while it runs, callbacks on the solving thread.  poll = iterations between two looks at the flag (0: default
+    100; the reference looks every iteration, msg_solver.cpp:82-87)."""
+    exe = _build_worker()
+    out = subprocess.run([exe, "256", str(poll)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["started"] == 1 and j["was_running"] == 1                       # the request arrived in the middle of the solve
+    assert j["stop_reason"] == "Прервано пользователем" and j["converged"] == 0      # msg_solver.cpp:82-87, msg_solver.hpp:96-97
+    assert j["iterations"] > 1 and j["last_callback_it"] == j["iterations"]  # final callback (msg_solver.cpp:193-195)
+    assert j["callback_on_worker_thread"] == 1 and j["main_is_not_worker"] == 1
+    assert j["stop_latency_ms"] < 1000

@@ -224,6 +224,83 @@ def test_stop_request_interrupts(isa):
     assert m.getIterations() == 200 and m.isStopRequested()
 
 
+def test_stop_requested_from_the_first_callback_stops_at_iteration_one(isa, oracle):
+    """msg_solver.cpp:82-87 polls the flag at the top of every iteration: a stop requested from the it == 1 callback
+    leaves iterations == 1 in the reference.  (Here the first iteration of a watched solve is a chunk of its own.)"""
+    s = isa.GridSystem(64, 64, 1.0, 2.0, 1.0, 2.0)
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-30, 100000)
+    m.setPrecisionEps(-1.0); m.setResidualEps(-1.0); m.setExactErrorEps(-1.0)
+    seen = []
+    m.setIterationCallback(lambda it, p, r, e: (seen.append(it), m.requestStop() if it == 1 else None))
+    x = m.solve(s.get_true_solution_vector())
+    assert m.getStopReason() == isa.StopCriterion.INTERRUPTED and m.getIterations() == 1 and seen == [0, 1, 1]
+    o = oracle.OracleGrid(64, 64).msg_solve(eps_precision=-1.0, eps_residual=-1.0, eps_exact_error=-1.0, max_iterations=1)
+    np.testing.assert_allclose(x, o.x, rtol=1e-13)              # x after exactly one step (alpha from a differently summed dot)
+
+
+def test_stop_reason_texts_are_the_references(isa):
+    """solver/msg_solver.hpp:85-100, verbatim: the strings are part of SolverResults.stop_reason and of the report."""
+    want = {0: "Достигнуто максимальное число итераций",
+            1: "Достигнута требуемая точность по норме разности xn и xn-1",
+            2: "Достигнута требуемая точность по норме невязки",
+            3: "Достигнута требуемая точность по норме разности с истинным решением",
+            4: "Прервано пользователем"}
+    s = isa.GridSystem(16, 16, 1.0, 2.0, 1.0, 2.0)
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-6, 10)
+    for k, text in want.items():
+        m.stop_reason = isa.StopCriterion(k)
+        assert m.getStopReasonText() == text
+    m.stop_reason = 17
+    assert m.getStopReasonText() == "Неизвестная причина остановки"
+
+
+@pytest.mark.parametrize("rule", ["msg", "rel2"])
+def test_apply_inside_an_iteration_callback_does_not_disturb_the_solve(isa, oracle, rule):
+    """The reference's apply is const: a callback may call it (or spmv) in the middle of a solve.  Here it works on
+    dedicated scratch vectors; the solve must still match the oracle exactly as without the call."""
+    N = 64
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    v = np.random.default_rng(5).uniform(-1, 1, s.size())
+    inside = []
+    if rule == "msg":
+        m = isa.MSGSolver(s, s.get_rhs(), 1e-9, 10000)
+        m.setExactErrorEps(-1.0)
+        m.setIterationCallback(lambda it, p, r, e: inside.append(s.apply(v)) if it in (1, 100) else None)
+        x = m.solve(s.get_true_solution_vector())
+        ref = og.msg_solve(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
+        assert (m.getIterations(), int(m.getStopReason())) == (ref.iterations, ref.stop_reason)
+    else:
+        m = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-9, 10 ** 5)
+        m.setIterationCallback(lambda it, p, r, e: inside.append(s.apply(v)) if it in (0, 7) else None)
+        x = m.solve(s.get_true_solution_vector())
+        ref = og.mf_solve(eps=1e-9, max_iterations=10 ** 5)
+        assert m.getIterations() == ref.iterations
+    assert len(inside) == 2 and all(np.array_equal(y, og.apply(v)) for y in inside)
+    assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+    s2 = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)                # the same solve without the calls: same bits
+    m2 = isa.MSGSolver(s2, s2.get_rhs(), 1e-9, 10000) if rule == "msg" else isa.MatrixFreeSolver(s2, s2.get_rhs(), 1e-9, 10 ** 5)
+    if rule == "msg":
+        m2.setExactErrorEps(-1.0)
+    else:
+        m2.setIterationCallback(lambda *a: None)
+    assert np.array_equal(m2.solve(s2.get_true_solution_vector()), x)
+
+
+def test_caller_supplied_true_solution_is_the_one_the_error_norm_uses(isa, oracle):
+    """MSGSolver::solve(true_solution) measures x - true_solution (msg_solver.cpp:64-72,132-139), whatever vector that is."""
+    N = 32
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    u2 = og.true_solution() + 0.25
+    m = isa.MSGSolver(s, s.get_rhs(), 1e-9, 10000)
+    m.setExactErrorEps(-1.0)
+    m.solve(u2)
+    ref = og.msg_solve(true_solution=u2, eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0)
+    assert m.getIterations() == ref.iterations
+    assert m.getFinalErrorNorm() == pytest.approx(ref.final_error_norm, rel=1e-12) and m.getFinalErrorNorm() > 0.2
+
+
 def test_dirichlet_solver_facade(isa, oracle):
     N = 64
     d = isa.DirichletSolver(N, N, 1.0, 2.0, 1.0, 2.0)
