@@ -117,6 +117,11 @@ int  mi355cg_get_rhs(mi355cg_handle h, double *out);
 int  mi355cg_get_true_solution(mi355cg_handle h, double *out);
 int  mi355cg_get_node_coords(mi355cg_handle h, double *xs, double *ys);
 int  mi355cg_set_rhs(mi355cg_handle h, const double *b);
+/* Opt-in (replaces the host loops of GridSystem::calculate_value / get_true_solution_vector,
+ * solver/grid_system.cpp:45-67,276-299): regenerate the right-hand side and the exact solution of the handle's cells on
+ * the GPU.  Same expression order; exp() is the device library's (<= 1 ulp from glibc's), so the vectors may differ from
+ * the reference's in the last bit, which is why mi355cg_create does NOT do this by default.                              */
+int  mi355cg_setup_on_device(mi355cg_handle h);
 
 /* ---- operator -------------------------------------------------------------------------------- */
 int  mi355cg_apply(mi355cg_handle h, const double *x, double *y);            /* host buffers   */
@@ -228,6 +233,7 @@ int  mi355cg_team_part(mi355cg_team t, int local_index, mi355cg_handle *part, in
  * this process's parts; checksum covers this process's parts.                                                           */
 int  mi355cg_team_get_vector(mi355cg_team t, int which, double *global_packed);
 int  mi355cg_team_checksum(mi355cg_team t, int which, double *out2);
+int  mi355cg_team_setup_on_device(mi355cg_team t);                     /* mi355cg_setup_on_device for every local part */
 int  mi355cg_team_set_profiling(mi355cg_team t, int enable);
 int  mi355cg_team_phase_times(mi355cg_team t, double *kernel_ms, double *comm_ms, double *wall_ms);   /* per iteration */
 

@@ -93,12 +93,21 @@ struct Context {
         : n(n_), m(m_), a(a_), b(b_), c(c_), d(d_) {
         check(mi355cg_create(n, m, a, b, c, d, MI355CG_F64, device, &h));
     }
+    // Optional: the same grid cut into parts that this process drives on one or several GPUs (LOCAL team, csrc/team.h).
+    // MSGSolver::solve then runs on the team; results are bit-identical to the single-GPU solve.
+    mi355cg_team team = nullptr;
+    void distribute(const std::vector<int>& devices, int decomp) {
+        if (csr) throw std::invalid_argument("a caller-supplied matrix cannot be distributed");
+        if (team) { mi355cg_team_destroy(team); team = nullptr; }
+        if (devices.size() > 1 || decomp != MI355CG_DECOMP_ROWS || !devices.empty())
+            check(mi355cg_team_create_local(n, m, a, b, c, d, (int)std::max<size_t>(devices.size(), 1), devices.data(), (int)devices.size(), decomp, &team));
+    }
     bool csr = false;
     // caller-supplied CSR matrix: the generic path of Solver(a, b, ...) (mi355cg_create_csr)
     Context(long long nrows, const int* row_map, const int* entries, const double* values, int device = 0) : csr(true) {
         check(mi355cg_create_csr(nrows, row_map, entries, values, device, &h));
     }
-    ~Context() { mi355cg_destroy(h); }
+    ~Context() { if (team) mi355cg_team_destroy(team); mi355cg_destroy(h); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     long long size() const { return mi355cg_size(h); }
@@ -184,6 +193,9 @@ public:
     }
     int get_n() const { return ctx_->n; }
     int get_m() const { return ctx_->m; }
+    // Extension (no reference counterpart: the reference is single-device): cut the grid into devices.size() parts, part r on
+    // GPU devices[r % size]; MI355CG_DECOMP_ROWS = row slabs, MI355CG_DECOMP_2D = (parts/2) x 2 blocks.  An empty list undoes it.
+    void distribute(const std::vector<int>& devices, int decomp = MI355CG_DECOMP_ROWS) { ctx_->distribute(devices, decomp); }
     const std::shared_ptr<mi355cg_compat::Context>& context() const { return ctx_; }
     friend std::ostream& operator<<(std::ostream& os, const GridSystem& g) {
         os << "GridSystem Matrix Information:\n  Dimensions: " << g.ctx_->n << "x" << g.ctx_->m << "\n  Domain: [" << g.ctx_->a << ", "
@@ -317,6 +329,16 @@ public:
             if (iteration_callback) iteration_callback(it, pr, rs, er);
         };
         mi355cg_results res;
+        mi355cg_team team = a.context()->team;
+        if (team) {
+            // the parts hold the grid's own right-hand side and exact solution; a foreign b or u needs the single-GPU path
+            std::vector<double> own(b.extent(0));
+            mi355cg_compat::check(mi355cg_get_rhs(h, own.data()));
+            for (size_t i = 0; i < own.size(); ++i)
+                if (own[i] != b(i)) throw std::invalid_argument("MSGSolver on a distributed grid: the right-hand side must be the grid's own");
+            mi355cg_compat::check(mi355cg_team_solve(team, &p, &mi355cg_compat::iter_trampoline, &cb,
+                                                     reinterpret_cast<const volatile int*>(&stop_requested), &res));
+        } else
         mi355cg_compat::check(mi355cg_solve(h, &p, &mi355cg_compat::iter_trampoline, &cb,
                                             reinterpret_cast<const volatile int*>(&stop_requested), &res));
         iterations = res.iterations;                                          // msg_solver.cpp:187-190
@@ -329,7 +351,8 @@ public:
                       << " мс\nНачальная невязка: " << initial_r_norm << "\nКонечная невязка: " << final_r_norm
                       << "\nСходимость: " << (converged ? "Да" : "Нет") << "\nПричина остановки: " << getStopReasonText() << std::endl;
         KokkosVector x("x", b.extent(0));
-        mi355cg_compat::check(mi355cg_get_solution(h, x.data()));
+        if (team) mi355cg_compat::check(mi355cg_team_get_vector(team, 0, x.data()));
+        else mi355cg_compat::check(mi355cg_get_solution(h, x.data()));
         return x;
     }
     // Same sections, labels and number formats as msg_solver.cpp:261-304 (the text is user-facing output).
@@ -556,6 +579,7 @@ public:
         n_internal = n; m_internal = m; a_bound = a; b_bound = b; c_bound = c; d_bound = d;
         solver.reset();
         grid = std::make_unique<GridSystem>(m_internal, n_internal, a_bound, b_bound, c_bound, d_bound);
+        if (!devices_.empty()) grid->distribute(devices_, decomp_);
     }
     void setSolverParameters(double eps_p, double eps_r, double eps_e, int max_iter) {
         eps_precision = eps_p; eps_residual = eps_r; eps_exact_error = eps_e; max_iterations = max_iter;
@@ -570,6 +594,11 @@ public:
     void setCompletionCallback(std::function<void(const SolverResults&)> cb) { completion_callback = std::move(cb); }
     void setVerbose(bool v) { verbose_ = v; }
     void setPollInterval(int iterations) { poll_interval_ = iterations; }         // see MSGSolver::setPollInterval
+    // Extension: solve on several GPUs of this process (see GridSystem::distribute).  Kept across setGridParameters.
+    void setDevices(const std::vector<int>& devices, int decomp = MI355CG_DECOMP_ROWS) {
+        devices_ = devices; decomp_ = decomp;
+        if (grid) grid->distribute(devices_, decomp_);
+    }
 
     SolverResults solve() {                                                       // dirichlet_solver.cpp:61-131
         if (!grid) throw std::runtime_error("Сетка не инициализирована");
@@ -587,6 +616,10 @@ public:
         r.solution = to_std(solution);
         r.true_solution = to_std(true_solution);
         r.residual.resize(r.solution.size());                                     // A x - b, one more apply (.cpp:147-161)
+        if (grid->context()->team) {                                              // x came from the parts: apply it on the whole-grid context
+            mi355cg_compat::check(mi355cg_apply(grid->context()->h, r.solution.data(), r.residual.data()));
+            for (size_t i = 0; i < r.residual.size(); ++i) r.residual[i] = r.residual[i] - grid->get_rhs()(i);
+        } else
         mi355cg_compat::check(mi355cg_get_true_residual(grid->context()->h, r.residual.data()));
         r.error.resize(r.solution.size());                                        // x - u (.cpp:164-180)
         for (size_t i = 0; i < r.error.size(); ++i) r.error[i] = r.solution[i] - r.true_solution[i];
@@ -626,4 +659,6 @@ private:
     SolverResults last_;
     bool verbose_ = true;
     int poll_interval_ = 0;
+    std::vector<int> devices_;
+    int decomp_ = MI355CG_DECOMP_ROWS;
 };

@@ -1118,6 +1118,35 @@ __global__ __launch_bounds__(kBlock) void k_pack(const PackGeom pg, const T* __r
         packed[i] = (double)storage[packed_to_storage(pg, i)];
 }
 
+// ---- device-side problem setup (opt-in) ---------------------------------------------------------------
+// Right-hand side and exact solution of the part's own cells straight into storage layout, in the reference's expression
+// order (grid_system.cpp:8-15,45-67,69-77).  The one difference from the host path: exp() is the device library's
+// (<= 1 ulp from glibc's), so b and u can differ from the reference's in the last bit -- hence opt-in.
+struct SetupArgs { PackGeom pg; double a, c, x_step, y_step, xk, yk; int n, m; };
+__device__ inline double setup_u(double x, double y) { return exp(x * x - y * y); }                              // solution()  :12-15
+__device__ inline double setup_f(double x, double y) { return 4 * (x * x + y * y) * exp(x * x - y * y); }        // function()  :8-10
+__global__ __launch_bounds__(kBlock) void k_setup(const SetupArgs s, double* __restrict__ b, double* __restrict__ u) {
+    const Geom& g = s.pg.g;
+    const long long stride = (long long)gridDim.x * kBlock;
+    const long long nb = (long long)s.pg.nb_rows * s.pg.wb;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < s.pg.pk_len; i += stride) {
+        int x, y;
+        if (i < nb) { const int k = (int)(i / s.pg.wb); y = s.pg.yb0 + k; x = s.pg.xb0 + (int)(i - (long long)k * s.pg.wb); }
+        else { const long long j = i - nb; const int k = (int)(j / s.pg.wu); y = s.pg.yu0 + k; x = s.pg.xu0 + (int)(j - (long long)k * s.pg.wu); }
+        const double xp = s.a + x * s.x_step, yp = s.c + y * s.y_step;                                          // calculate_x / calculate_y :69-77
+        double value = setup_f(xp, yp);                                                                          // calculate_value :45-67
+        const bool left_b = (x - 1 == 0 && y >= s.m / 2 && y <= s.m) || (x - 1 == s.n / 2 && y >= 0 && y <= s.m / 2);      // is_left_boundary(x-1, y) :17-22
+        const bool bottom_b = (y - 1 == 0 && x >= s.n / 2 && x <= s.n) || (y - 1 == s.m / 2 && x >= 0 && x <= s.n / 2);    // is_bottom_boundary(x, y-1) :38-43
+        if (left_b) value -= s.xk * setup_u(s.a + (x - 1) * s.x_step, yp);
+        if (x + 1 == s.n) value -= s.xk * setup_u(s.a + (x + 1) * s.x_step, yp);
+        if (y + 1 == s.m) value -= s.yk * setup_u(xp, s.c + (y + 1) * s.y_step);
+        if (bottom_b) value -= s.yk * setup_u(xp, s.c + (y - 1) * s.y_step);
+        const long long off = row_off(g, y) - g.base0 + x;
+        b[off] = value;
+        u[off] = setup_u(xp, yp);
+    }
+}
+
 // out = a - b over the owned flat range (true residual A x - b; dirichlet_solver.cpp:156-158)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_sub(long long begin, long long len, const T* a, const T* b, T* out) {

@@ -97,6 +97,7 @@ struct mi355cg_ctx {
     double* partR_h = nullptr;          // pinned
 
     std::vector<double> rhs_h, u_h;     // host copies (owned cells, the part's packed order)
+    bool host_rhs_valid = true, host_u_valid = true;     // false after mi355cg_setup_on_device until somebody asks for the host copy
     bool have_u_dev = false, solved = false;
     // generic CSR handle (mi355cg_create_csr): vectors are plain length-n arrays, the operator is this matrix
     bool is_csr = false;
@@ -431,8 +432,14 @@ int alloc_vec(double** p, long long n) {
     return MI355CG_OK;
 }
 
+int ensure_host_copies(mi355cg_ctx* c) {        // device-generated problem data: fetch the host copies on first use
+    if (!c->host_rhs_valid) { c->rhs_h.resize(c->pk_len); if (int rc = download_packed<double>(c, c->b, c->rhs_h.data())) return rc; c->host_rhs_valid = true; }
+    if (!c->host_u_valid) { c->u_h.resize(c->pk_len); if (int rc = download_packed<double>(c, c->u, c->u_h.data())) return rc; c->host_u_valid = true; }
+    return MI355CG_OK;
+}
 int ensure_u_on_device(mi355cg_ctx* c) {
     if (c->have_u_dev) return MI355CG_OK;
+    if (!c->host_u_valid) return fail(MI355CG_ERR_STATE, "no exact solution on host or device");
     if (int rc = upload_packed<double>(c, c->u_h.data(), c->u)) return rc;
     c->have_u_dev = true;
     return MI355CG_OK;
@@ -784,10 +791,17 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     // or kernel of the context and wipe it (seen as a right-hand side of zeros -> "converged" at iteration 0).
     HIPCK(hipDeviceSynchronize());
 
-    // problem data on the host in the part's packed order, then into storage layout on the device
-    c->rhs_h.resize(c->pk_len); c->u_h.resize(c->pk_len);
-    grid_fill_box(gp, c->g.y_lo, c->g.y_hi, s_lo * kStripCols, s_hi == ns_all ? gp.n : s_hi * kStripCols, c->rhs_h.data(), c->u_h.data(), nullptr, nullptr);
-    if ((rc = upload_packed<double>(c, c->rhs_h.data(), c->b))) return cleanup();
+    if (env_int("MI355CG_DEVICE_SETUP", 0)) {
+        // opt-in: b and u generated on the device, no host pass and no upload; <= 1 ulp from the host values
+        c->host_rhs_valid = false; c->host_u_valid = false;
+        if ((rc = mi355cg_setup_on_device(c))) return cleanup();
+    } else {
+        // problem data on the host in the part's packed order (bit-identical to the reference on the same libm), then into
+        // storage layout on the device
+        c->rhs_h.resize(c->pk_len); c->u_h.resize(c->pk_len);
+        grid_fill_box(gp, c->g.y_lo, c->g.y_hi, s_lo * kStripCols, s_hi == ns_all ? gp.n : s_hi * kStripCols, c->rhs_h.data(), c->u_h.data(), nullptr, nullptr);
+        if ((rc = upload_packed<double>(c, c->rhs_h.data(), c->b))) return cleanup();
+    }
     *out = c;
     return MI355CG_OK;
 }
@@ -868,6 +882,8 @@ int mi355cg_create_csr(long long nrows, const int* row_map, const int* entries, 
 int mi355cg_set_true_solution(mi355cg_handle c, const double* u) {
     if (!c || !u) return fail(MI355CG_ERR_INVALID, "null argument");
     HIPCK(hipSetDevice(c->device));
+    c->host_u_valid = true;
+    c->u_h.resize(c->pk_len);
     std::memcpy(c->u_h.data(), u, sizeof(double) * c->pk_len);
     if (int rc = upload_packed<double>(c, c->u_h.data(), c->u)) return rc;
     c->have_u_dev = true;
@@ -898,11 +914,13 @@ long long mi355cg_size(mi355cg_handle c) { return c ? c->gp.size : -1; }
 
 int mi355cg_get_rhs(mi355cg_handle c, double* out) {
     if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (int rc = ensure_host_copies(c)) return rc;
     std::memcpy(out, c->rhs_h.data(), sizeof(double) * c->pk_len);
     return MI355CG_OK;
 }
 int mi355cg_get_true_solution(mi355cg_handle c, double* out) {
     if (!c || !out) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (int rc = ensure_host_copies(c)) return rc;
     std::memcpy(out, c->u_h.data(), sizeof(double) * c->pk_len);
     return MI355CG_OK;
 }
@@ -913,9 +931,28 @@ int mi355cg_get_node_coords(mi355cg_handle c, double* xs, double* ys) {
     grid_fill_box(c->gp, c->g.y_lo, c->g.y_hi, c->s_lo * kStripCols, c->s_hi == ns_all ? c->gp.n : c->s_hi * kStripCols, nullptr, nullptr, xs, ys);
     return MI355CG_OK;
 }
+// regenerate b and u of this handle's cells ON THE DEVICE (k_setup).  Opt-in: the device exp() is within
+// 1 ulp of glibc's, not identical, so the vectors -- and with them every later number -- may differ from the reference's
+// in the last bits.  The host copies are fetched lazily.
+int mi355cg_setup_on_device(mi355cg_handle c) {
+    if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
+    if (c->is_csr) return fail(MI355CG_ERR_INVALID, "a CSR handle has no grid to set up");
+    HIPCK(hipSetDevice(c->device));
+    if (c->is_slab) HIPCK(hipDeviceSynchronize());
+    SetupArgs s{};
+    s.pg = c->pg; s.a = c->gp.a; s.c = c->gp.c; s.x_step = c->gp.x_step; s.y_step = c->gp.y_step; s.xk = c->gp.x_k; s.yk = c->gp.y_k;
+    s.n = c->gp.n; s.m = c->gp.m;
+    if (c->pk_len > 0) hipLaunchKernelGGL(k_setup, dim3(flat_grid(c->pk_len)), dim3(kBlock), 0, c->stream, s, c->b, c->u);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->have_u_dev = true; c->host_rhs_valid = false; c->host_u_valid = false;
+    return MI355CG_OK;
+}
 int mi355cg_set_rhs(mi355cg_handle c, const double* b) {
     if (!c || !b) return fail(MI355CG_ERR_INVALID, "null argument");
     HIPCK(hipSetDevice(c->device));
+    c->host_rhs_valid = true;
+    c->rhs_h.resize(c->pk_len);
     std::memcpy(c->rhs_h.data(), b, sizeof(double) * c->pk_len);
     return upload_packed<double>(c, c->rhs_h.data(), c->b);
 }

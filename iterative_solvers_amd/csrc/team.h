@@ -727,6 +727,7 @@ int mi355cg_team_get_vector(mi355cg_team t, int which, double* global_packed) {
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
         std::vector<double> own(std::max<long long>(c->pk_len, 1));
+        if (which == 2 || which == 3) { if (int rc = ensure_host_copies(c)) return rc; }
         if (which == 2) own = c->rhs_h;
         else if (which == 3) own = c->u_h;
         else if (which == 0 || which == 1) { if (int rc = download_packed<double>(c, which == 0 ? c->x : c->r, own.data())) return rc; }
@@ -745,6 +746,13 @@ int mi355cg_team_checksum(mi355cg_team t, int which, double* out2) {
     hdd s[2] = {{0, 0}, {0, 0}};
     for (auto& p : t->parts) if (int rc = ctx_checksum(p.c, which, s)) return rc;
     out2[0] = s[0].hi + s[0].lo; out2[1] = s[1].hi + s[1].lo;
+    return MI355CG_OK;
+}
+
+// mi355cg_setup_on_device for every part this process drives
+int mi355cg_team_setup_on_device(mi355cg_team t) {
+    if (!t) return fail(MI355CG_ERR_INVALID, "null team");
+    for (auto& p : t->parts) if (int rc = mi355cg_setup_on_device(p.c)) return rc;
     return MI355CG_OK;
 }
 

@@ -439,6 +439,9 @@ class Team:
         _capi.check(self._lib.mi355cg_team_checksum(self._h, which, o))
         return o[0], o[1]
 
+    def setup_on_device(self):
+        _capi.check(self._lib.mi355cg_team_setup_on_device(self._h))
+
     def set_profiling(self, on: bool):
         _capi.check(self._lib.mi355cg_team_set_profiling(self._h, 1 if on else 0))
 

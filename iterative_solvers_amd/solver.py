@@ -128,6 +128,10 @@ class _Handle:
         _capi.check(rc)
         return res
 
+    def setup_on_device(self):
+        """Opt-in: regenerate b and u on the GPU (<= 1 ulp from the host values)."""
+        _capi.check(self._lib.mi355cg_setup_on_device(self._h))
+
     def set_profiling(self, on: bool):
         _capi.check(self._lib.mi355cg_set_profiling(self._h, 1 if on else 0))
 

@@ -73,6 +73,17 @@ int main(int argc, char** argv) {
         std::printf("\"ds_saved\": %d, \"ds_roundtrip\": %d, \"ds_method\": \"%s\",\n", saved ? 1 : 0, same ? 1 : 0, ds.getMethodName().empty() ? "" : "set");
         jvec("ds_true_solution", r.true_solution); jvec("ds_x_coords", r.x_coords); jvec("ds_y_coords", r.y_coords);
         std::printf("\"ds_stop_reason\": \"%s\",\n", r.stop_reason.c_str());
+        // the same facade on a distributed grid (extension: one process, several parts -- here 4 parts in a 2 x 2 split sharing GPU 0)
+        DirichletSolver dd(N, N, 1.0, 2.0, 1.0, 2.0);
+        dd.setVerbose(false);
+        dd.setSolverParameters(1e-8, 1e-8, 1e-8, max_it);
+        dd.setDevices({0, 0, 0, 0}, N >= 256 ? MI355CG_DECOMP_2D : MI355CG_DECOMP_ROWS);
+        std::vector<double> cb_its;
+        dd.setIterationCallback([&](int it, double, double, double) { cb_its.push_back(it); });
+        SolverResults q = dd.solve();
+        const bool same_dist = q.iterations == r.iterations && q.converged == r.converged && q.stop_reason == r.stop_reason &&
+                               q.solution == r.solution && q.residual == r.residual && q.residual_norm == r.residual_norm && q.error_norm == r.error_norm;
+        std::printf("\"dist_same_as_one_gpu\": %d, \"dist_iterations\": %d, \"dist_callbacks\": %d,\n", same_dist ? 1 : 0, q.iterations, (int)cb_its.size());
     }
     {   // matrix-free pair
         MatrixFreeSystem sys(N, N, 1.0, 2.0, 1.0, 2.0);

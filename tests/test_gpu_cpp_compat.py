@@ -36,7 +36,7 @@ def test_compat_headers_compile_warning_free():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [16, 64])
+@pytest.mark.parametrize("N", [16, 64, 258])
 def test_cpp_dropin_matches_oracle(N):
     from oracle.oracle import OracleGrid
     exe = build_driver()
@@ -65,6 +65,8 @@ def test_cpp_dropin_matches_oracle(N):
     assert np.array_equal(np.array(j["ds_residual"]), og.apply(sol) - og.rhs())
     assert np.array_equal(np.array(j["ds_error"]), sol - og.true_solution())
     assert j["ds_error_norm"] == pytest.approx(ref.final_error_norm, rel=1e-9)
+    # the facade on a distributed grid (4 parts driven by this process): bit-identical results
+    assert (j["dist_same_as_one_gpu"], j["dist_iterations"]) == (1, ref.iterations) and j["dist_callbacks"] >= 3
     # matrix-free pair
     mf = og.mf_solve(eps=1e-8, max_iterations=10 ** 6)
     assert (j["mf_iterations"], j["mf_completed_ok"]) == (mf.iterations, 1)
