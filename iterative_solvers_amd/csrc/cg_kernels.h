@@ -71,7 +71,21 @@ __host__ __device__ inline bool node_interior(const Geom& g, int x, int y) {
 // gc (2-D decomposition): bit 0 = the column left of the panel's first strip belongs to another part (a ghost
 // column of this part), bit 1 = the same on the right of its last strip.
 struct Panel { int y0, y1, s0, ns, ty, nchunks, item0, gc; };
-struct WorkList { Panel p[kMaxPanels]; int np; int nitems; };
+// XCD classes: on this part the even XCDs run the same work 6-11 % slower than the odd ones (per-wave timelines,
+// profiles/r02_wave_timing.txt), and workgroups land on XCD blockIdx % 8.  With ncls == 2 the items [cls0[0], cls0[1]) --
+// cut a few per cent shorter -- are served by the even-numbered workgroups only and the items [cls0[1], cls0[2]) by the odd
+// ones.  A wrong guess about the placement costs balance, never correctness.
+struct WorkList { Panel p[kMaxPanels]; int np; int nitems; int ncls; int cls0[3]; };
+// the item indices a wave takes: first, first + step, ... < end
+struct ItemSeq { int first, step, begin, end; };
+__device__ inline ItemSeq item_seq(const WorkList& wl, int wave) {
+    if (wl.ncls == 2) {
+        const int cls = blockIdx.x & 1, nb = (gridDim.x + 1 - cls) >> 1;
+        const int begin = cls ? wl.cls0[1] : wl.cls0[0], end = cls ? wl.cls0[2] : wl.cls0[1];
+        return ItemSeq{begin + (int)(blockIdx.x >> 1) * kWaves + wave, nb * kWaves, begin, end};
+    }
+    return ItemSeq{(int)blockIdx.x * kWaves + wave, (int)gridDim.x * kWaves, 0, wl.nitems};
+}
 
 // ---- CG state carried on the device ----------------------------------------------------------------
 struct CgState {
@@ -202,6 +216,24 @@ __device__ inline dd block_reduce_dd(dd v, double* lds) {
     for (int k = 1; k < kWaves; ++k) t = dd_add(t, dd{lds[2 * k], lds[2 * k + 1]});
     return t;
 }
+// The first two partial pairs of a thread (i = t, t + 256), loaded EARLY: the consumer kernels issue these loads before they
+// wait for the CG state (which says whether the solve is already done), so the two dependent ~1.5 us round trips of the
+// prologue -- state, then partials -- overlap.  reduce_parts_dd_pre consumes them in exactly reduce_parts_dd's order.
+struct PreParts { double hi0, lo0, hi1, lo1; };
+__device__ inline PreParts prefetch_parts(const double* __restrict__ part_hi, const double* __restrict__ part_lo, int n, int es) {
+    PreParts p{0.0, 0.0, 0.0, 0.0};
+    const int i0 = threadIdx.x, i1 = threadIdx.x + kBlock;
+    if (i0 < n) { p.hi0 = part_hi[(long long)i0 * es]; p.lo0 = part_lo[(long long)i0 * es]; }
+    if (i1 < n) { p.hi1 = part_hi[(long long)i1 * es]; p.lo1 = part_lo[(long long)i1 * es]; }
+    return p;
+}
+__device__ inline dd reduce_parts_dd_pre(const PreParts& pre, const double* __restrict__ part_hi, const double* __restrict__ part_lo, int n, int es, double* lds) {
+    dd v = dd_zero();
+    if ((int)threadIdx.x < n) v = dd_add(v, dd{pre.hi0, pre.lo0});
+    if ((int)threadIdx.x + kBlock < n) v = dd_add(v, dd{pre.hi1, pre.lo1});
+    for (int i = threadIdx.x + 2 * kBlock; i < n; i += kBlock) v = dd_add(v, dd{part_hi[(long long)i * es], part_lo[(long long)i * es]});
+    return block_reduce_dd(v, lds);
+}
 // partial pairs: hi words at part_hi[i*es], lo words at part_lo[i*es]
 __device__ inline dd reduce_parts_dd(const double* __restrict__ part_hi, const double* __restrict__ part_lo, int n, int es, double* lds) {
     dd v = dd_zero();
@@ -252,8 +284,9 @@ __device__ inline void write_state_after_decision(CgState* out, HistEntry* hist,
 
 // Reduce the update kernel's partials (only the fields the rule needs) and decide.
 __device__ inline Decision reduce_and_decide(const StateLite& s, const RuleParams& rp, const double* partB,
-                                             int nB, int strideB, int esB, int want_diag, double* lds) {
-    const double rr = dd_value(reduce_parts_dd(partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, esB, lds));
+                                             int nB, int strideB, int esB, int want_diag, double* lds, const PreParts* pre_rr = nullptr) {
+    const double rr = pre_rr ? dd_value(reduce_parts_dd_pre(*pre_rr, partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, esB, lds))
+                             : dd_value(reduce_parts_dd(partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, esB, lds));
     double rmax = 0, dmax = 0, emax = 0, d2 = 0, e2 = 0;
     if (rp.rule == 0 || want_diag) {
         rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, esB, lds);
@@ -477,13 +510,13 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     const Geom& g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // wave-uniform -> SGPR item decode
-    const int nwaves = gridDim.x * kWaves;
+    const ItemSeq seq = item_seq(a.wl, wave);
     MI355CG_WT_BEGIN
     struct Raw { vec_t r, p; T re, pe; };
 
     // ---- fetch cursor ----
-    int f_item = blockIdx.x * kWaves + wave;
-    bool f_have = f_item < a.wl.nitems;
+    int f_item = seq.first;
+    bool f_have = f_item < seq.end;
     ItemAddr F{};
     int f_idx = 0, f_so = 0, f_y = 0;
     rsrc_t rs_p = make_rsrc(a.pin), rs_r = make_rsrc(a.pin);
@@ -495,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     };
     auto fetch = [&]() -> Raw {
         if (f_have && f_idx > F.nrows) {                         // lazily: the compute cursor may still need F (see promote)
-            f_item += nwaves; f_have = f_item < a.wl.nitems;
+            f_item += seq.step; f_have = f_item < seq.end;
             if (f_have) enter(f_item);
         }
         const bool own = f_idx >= 0 && f_idx < F.nrows;
@@ -544,10 +577,11 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
 
     T beta = (T)0;
     if (FUSED) {
+        const PreParts pre = prefetch_parts(a.partB + FB_RR * a.strideB, a.partB + (FB_RR + FB_LO) * a.strideB, a.nB, a.esB);
         const StateLite s = load_state_lite(a.s_in);
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
         MI355CG_WT_STAMP(1)
-        const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, a.want_diag, lds);
+        const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, a.want_diag, lds, &pre);
         MI355CG_WT_STAMP(2)
         if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, a.s_in, s, d);
         if (d.done) return;
@@ -612,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                 }
                 if (c_idx == C.nrows) {                            // that was the halo row ahead of the last own row
                     if (FUSED && a.store_ghosts && is_ghost(c_y)) buf_store(pn, rs_po, C.vo_last, c_so);
-                    c_item += nwaves; c_have = c_item < a.wl.nitems;
+                    c_item += seq.step; c_have = c_item < seq.end;
                     if (c_have) promote();
                 } else ++c_idx;
             }
@@ -780,19 +814,19 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     const Geom& g = a.g;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int nwaves = gridDim.x * kWaves;
+    const ItemSeq seq = item_seq(a.wl, wave);
     MI355CG_WT_BEGIN
     constexpr bool FULL = XM == 1;
     struct Raw { vec_t p, r, x, u, pp; T pe; };
 
     // ---- fetch cursor (see k_stencil) ----
-    int f_item = blockIdx.x * kWaves + wave;
-    bool f_have = f_item < a.wl.nitems;
+    int f_item = seq.first;
+    bool f_have = f_item < seq.end;
     ItemAddr F{};
     int f_idx = 0, f_so = 0, f_y = 0;
     rsrc_t rs_p = make_rsrc(a.p), rs_r = rs_p, rs_x = rs_p, rs_pp = rs_p, rs_u = rs_p;
     auto enter = [&](int idx) {
-        F = item_addr<T, VEC, DESC>(g, decode_item(a.wl, a.reverse ? a.wl.nitems - 1 - idx : idx), lane);
+        F = item_addr<T, VEC, DESC>(g, decode_item(a.wl, a.reverse ? seq.end - 1 - (idx - seq.begin) : idx), lane);   // reversed within the wave's class
         rs_p = make_rsrc(a.p + F.base_el);
         rs_r = make_rsrc(a.r + F.base_el);
         rs_x = make_rsrc(XM != 0 ? a.x + F.base_el : a.p + F.base_el);
@@ -803,7 +837,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     // `own`: the row is one of this item's rows (its r / x / u / previous direction are needed, and its edge element)
     auto fetch = [&]() -> Raw {
         if (f_have && f_idx > F.nrows) {
-            f_item += nwaves; f_have = f_item < a.wl.nitems;
+            f_item += seq.step; f_have = f_item < seq.end;
             if (f_have) enter(f_item);
         }
         const bool own = f_have && f_idx >= 0 && f_idx < F.nrows;
@@ -846,11 +880,12 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
 
+    const PreParts pre = prefetch_parts(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA);
     const StateLite s = load_state_lite(a.s_in);
     if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
     double alpha_d, rz = 0.0;
     {
-        const double pap = dd_value(reduce_parts_dd(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
+        const double pap = dd_value(reduce_parts_dd_pre(pre, a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
         if (a.rule == 0) {
             rz = dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
             alpha_d = rz / pap;                       // msg_solver.cpp:102
@@ -922,7 +957,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                     p_b = c.p; c = w;
                 }
                 if (c_idx == C.nrows) {
-                    c_item += nwaves; c_have = c_item < a.wl.nitems;
+                    c_item += seq.step; c_have = c_item < seq.end;
                     if (c_have) promote();
                 } else ++c_idx;
             }

@@ -17,6 +17,8 @@ VARIANTS = [
     {"MI355CG_DEPTH": "3", "MI355CG_ITEM_ROWS": "1"},
     {"MI355CG_BLOCKS": "37"},
     {"MI355CG_WAVES": "256", "MI355CG_ITEM_ROWS": "5"},
+    {"MI355CG_XCD_SKEW": "0"},                              # no even/odd-XCD classes
+    {"MI355CG_XCD_SKEW": "25", "MI355CG_ITEM_ROWS": "9"},
 ]
 
 

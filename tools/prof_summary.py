@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    for key in ("k_stencil", "k_update_st", "k_update2d", "k_update", "k_check", "k_reduce_parts", "k_pack", "k_unpack", "k_sub", "k_resid2"):
+    for key in ("k_stencil", "k_update_st", "k_update", "k_check", "k_flush_x", "k_team_record", "k_team_stop", "k_cols", "k_pack", "k_unpack", "k_sub", "k_resid2", "k_checksum", "k_setup"):
         if key in name:
             tag = key
             if key == "k_stencil":
