@@ -509,3 +509,50 @@ def test_n2048_against_long_oracle_runs(isa):
     assert (m.getIterations(), int(m.getStopReason())) == (mr["iterations"], mr["stop_reason"])
     assert abs(m.getFinalResidualNorm() - mr["final_residual_norm"]) / mf["initial_r_norm"] <= REL_TOL
     assert m.getFinalErrorNorm() == pytest.approx(mr["final_error_norm"], rel=1e-6)
+
+
+def test_n4096_converged_against_the_oracle(isa):
+    """BASELINE config 2 at full size, CONVERGED: the CPU oracle's serial solves of N = 4096 (12.6 M unknowns; 1.5 h per
+    solve on one core, tests/golden/oracle_n4096.json made by tests/golden/make_oracle_n4096.py) against the GPU path:
+    same iteration count and stop reason, final residual norms within north_star's 1e-12 * ||b||_2, the solution on a
+    strided sample.  (matrix_free_system.cpp:409,472; msg_solver.cpp:144-162)"""
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_n4096.json")) as f:
+        ref = json.load(f)
+    N = 4096
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    mf = ref["mf_4096"]
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+    x = sol.solve()
+    assert sol.getIterations() == mf["iterations"] and sol.last_results.converged == mf["converged"]
+    assert sol.last_results.initial_r_norm2 == pytest.approx(mf["initial_r_norm"], rel=1e-10)
+    assert abs(sol.last_results.r_norm2 - mf["r_norm"]) / mf["initial_r_norm"] <= REL_TOL
+    xs = np.array([float.fromhex(h) for h in mf["x"]["hex"]])
+    assert np.abs(x[::mf["x"]["stride"]] - xs).max() <= 1e-9 * np.abs(xs).max()
+    assert abs(np.abs(x).max() - mf["x"]["max_norm"]) <= 1e-9 * mf["x"]["max_norm"]
+    if "mfdiag_4096" in ref:          # the reference's per-iteration report (2-norms, TRUE residual), sampled
+        md = ref["mfdiag_4096"]
+        got = {}
+        sol2 = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+        sol2.setIterationCallback(lambda it, p, r, e: got.__setitem__(it, (p, r, e)))
+        sol2.solve(s.get_true_solution_vector())
+        assert sol2.getIterations() == md["iterations"] and len(got) == md["iterations"]
+        for it, p, r, e in md["callbacks"]:
+            gp, gr, ge = got[int(it)]
+            assert abs(gr - r) / mf["initial_r_norm"] <= 1e-10 and gp == pytest.approx(p, rel=1e-5, abs=1e-9) and ge == pytest.approx(e, rel=1e-5)
+    if "msg_4096" in ref:
+        mr = ref["msg_4096"]
+        m = isa.MSGSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+        m.setPrecisionEps(1e-8); m.setResidualEps(1e-8); m.setExactErrorEps(-1.0)
+        cbs = []
+        m.setIterationCallback(lambda *a: cbs.append(a))
+        xm = m.solve(s.get_true_solution_vector())
+        assert (m.getIterations(), int(m.getStopReason()), m.hasConverged()) == (mr["iterations"], mr["stop_reason"], mr["converged"])
+        assert abs(m.getFinalResidualNorm() - mr["final_residual_norm"]) / mf["initial_r_norm"] <= REL_TOL
+        assert abs(m.last_results.r_norm2 - mr["r_norm2"]) / mf["initial_r_norm"] <= REL_TOL
+        assert m.getFinalErrorNorm() == pytest.approx(mr["final_error_norm"], rel=1e-6)
+        assert m.getFinalPrecision() == pytest.approx(mr["final_precision"], rel=1e-6)
+        assert [c[0] for c in cbs] == [c[0] for c in mr["callbacks"]]
+        assert np.abs(np.array([c[2] for c in cbs]) - np.array([c[2] for c in mr["callbacks"]])).max() / mf["initial_r_norm"] <= 1e-10
+        xs = np.array([float.fromhex(h) for h in mr["x"]["hex"]])
+        assert np.abs(xm[::mr["x"]["stride"]] - xs).max() <= 1e-9 * np.abs(xs).max()
