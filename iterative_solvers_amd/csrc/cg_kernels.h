@@ -234,6 +234,20 @@ __device__ inline dd reduce_parts_dd_pre(const PreParts& pre, const double* __re
     for (int i = threadIdx.x + 2 * kBlock; i < n; i += kBlock) v = dd_add(v, dd{part_hi[(long long)i * es], part_lo[(long long)i * es]});
     return block_reduce_dd(v, lds);
 }
+// the same for one max field
+struct PreMax { double v0, v1; };
+__device__ inline PreMax prefetch_max(const double* __restrict__ part, int n, int es) {
+    PreMax p{0.0, 0.0};
+    if ((int)threadIdx.x < n) p.v0 = part[(long long)threadIdx.x * es];
+    if ((int)threadIdx.x + kBlock < n) p.v1 = part[(long long)(threadIdx.x + kBlock) * es];
+    return p;
+}
+template <bool IS_MAX> __device__ inline double block_reduce(double v, double* lds);
+__device__ inline double reduce_max_pre(const PreMax& pre, const double* __restrict__ part, int n, int es, double* lds) {
+    double v = fmax(pre.v0, pre.v1);
+    for (int i = threadIdx.x + 2 * kBlock; i < n; i += kBlock) v = fmax(v, part[(long long)i * es]);
+    return block_reduce<true>(v, lds);
+}
 // partial pairs: hi words at part_hi[i*es], lo words at part_lo[i*es]
 __device__ inline dd reduce_parts_dd(const double* __restrict__ part_hi, const double* __restrict__ part_lo, int n, int es, double* lds) {
     dd v = dd_zero();
@@ -284,14 +298,21 @@ __device__ inline void write_state_after_decision(CgState* out, HistEntry* hist,
 
 // Reduce the update kernel's partials (only the fields the rule needs) and decide.
 __device__ inline Decision reduce_and_decide(const StateLite& s, const RuleParams& rp, const double* partB,
-                                             int nB, int strideB, int esB, int want_diag, double* lds, const PreParts* pre_rr = nullptr) {
+                                             int nB, int strideB, int esB, int want_diag, double* lds, const PreParts* pre_rr = nullptr,
+                                             const PreMax* pre_max = nullptr /* rmax, dmax, emax */) {
     const double rr = pre_rr ? dd_value(reduce_parts_dd_pre(*pre_rr, partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, esB, lds))
                              : dd_value(reduce_parts_dd(partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, esB, lds));
     double rmax = 0, dmax = 0, emax = 0, d2 = 0, e2 = 0;
     if (rp.rule == 0 || want_diag) {
-        rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, esB, lds);
-        dmax = reduce_parts<true>(partB + FB_DMAX * strideB, nB, esB, lds);
-        if (rp.use_u) emax = reduce_parts<true>(partB + FB_EMAX * strideB, nB, esB, lds);
+        if (pre_max) {
+            rmax = reduce_max_pre(pre_max[0], partB + FB_RMAX * strideB, nB, esB, lds);
+            dmax = reduce_max_pre(pre_max[1], partB + FB_DMAX * strideB, nB, esB, lds);
+            if (rp.use_u) emax = reduce_max_pre(pre_max[2], partB + FB_EMAX * strideB, nB, esB, lds);
+        } else {
+            rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, esB, lds);
+            dmax = reduce_parts<true>(partB + FB_DMAX * strideB, nB, esB, lds);
+            if (rp.use_u) emax = reduce_parts<true>(partB + FB_EMAX * strideB, nB, esB, lds);
+        }
     }
     if (want_diag) {
         d2 = dd_value(reduce_parts_dd(partB + FB_D2 * strideB, partB + (FB_D2 + FB_LO) * strideB, nB, esB, lds));
@@ -325,19 +346,32 @@ __device__ inline void store_partial(double* p, double v, bool publish) {
     else *p = v;
 }
 // which: 0 = stencil partials (FA_*), 1 = update partials (FB_*).  Called by all threads of one block.
+// All loads of all fields are issued first (one memory round trip instead of one per field), then reduced field by field
+// in reduce_parts_dd's order.
 __device__ inline void emit_record(int which, const double* part, int stride, const RecSpec& rs, double* lds) {
     __shared__ double rec[kRecWords];
     if (threadIdx.x < kRecWords) rec[threadIdx.x] = 0.0;
-    __syncthreads();
     const int nsum = which == 0 ? kNumSumsA : kNumSumsB, lo_off = which == 0 ? FA_LO : FB_LO;
-    for (int f = 0; f < nsum; ++f) {
-        const dd t = reduce_parts_dd(part + f * stride, part + (f + lo_off) * stride, rs.nslots, 1, lds);
+    constexpr int kMaxSums = 3;
+    PreParts pre[kMaxSums];
+    PreMax pmax[3] = {{0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+    for (int f = 0; f < kMaxSums; ++f) if (f < nsum) pre[f] = prefetch_parts(part + f * stride, part + (f + lo_off) * stride, rs.nslots, 1);
+    if (which == 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pmax[k] = prefetch_max(part + (FB_RMAX + k) * stride, rs.nslots, 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < kMaxSums; ++f) if (f < nsum) {
+        const dd t = reduce_parts_dd_pre(pre[f], part + f * stride, part + (f + lo_off) * stride, rs.nslots, 1, lds);
         if (threadIdx.x == 0) { rec[f] = t.hi; rec[f + lo_off] = t.lo; }
     }
     if (which == 1) {
-        for (int f = FB_RMAX; f < FB_RMAX + 3; ++f) {
-            const double t = reduce_parts<true>(part + f * stride, rs.nslots, 1, lds);
-            if (threadIdx.x == 0) rec[f] = t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double t = reduce_max_pre(pmax[k], part + (FB_RMAX + k) * stride, rs.nslots, 1, lds);
+            if (threadIdx.x == 0) rec[FB_RMAX + k] = t;
         }
         if (threadIdx.x == 0 && rs.stop_req) rec[kRecStopWord] = *(const volatile int*)rs.stop_req ? 1.0 : 0.0;
     }
@@ -578,10 +612,15 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     T beta = (T)0;
     if (FUSED) {
         const PreParts pre = prefetch_parts(a.partB + FB_RR * a.strideB, a.partB + (FB_RR + FB_LO) * a.strideB, a.nB, a.esB);
+        PreMax pmax[3] = {{0, 0}, {0, 0}, {0, 0}};
+        if (MSG) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pmax[k] = prefetch_max(a.partB + (FB_RMAX + k) * a.strideB, a.nB, a.esB);
+        }
         const StateLite s = load_state_lite(a.s_in);
         if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
         MI355CG_WT_STAMP(1)
-        const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, a.want_diag, lds, &pre);
+        const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, a.want_diag, lds, &pre, MSG ? pmax : nullptr);
         MI355CG_WT_STAMP(2)
         if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, a.s_in, s, d);
         if (d.done) return;
@@ -881,13 +920,16 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
 
     const PreParts pre = prefetch_parts(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA);
+    PreParts pre_rz{0, 0, 0, 0};
+    if (FULL) pre_rz = prefetch_parts(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA);
     const StateLite s = load_state_lite(a.s_in);
     if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
     double alpha_d, rz = 0.0;
     {
         const double pap = dd_value(reduce_parts_dd_pre(pre, a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
         if (a.rule == 0) {
-            rz = dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
+            rz = FULL ? dd_value(reduce_parts_dd_pre(pre_rz, a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds))
+                      : dd_value(reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds));
             alpha_d = rz / pap;                       // msg_solver.cpp:102
         } else {
             alpha_d = s.rr / pap;                     // matrix_free_system.cpp:419

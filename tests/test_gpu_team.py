@@ -47,10 +47,11 @@ def test_local_team_rel2_is_bit_identical_to_one_gpu(n, world, decomp):
     assert np.array_equal(t.vector(1), s1._handle.recursive_residual())
     assert np.array_equal(t.vector(2), s1.get_rhs()) and np.array_equal(t.vector(3), s1.get_true_solution_vector())
     assert t.checksum(0) == tuple(_cs(s1, 0)) and t.checksum(1) == tuple(_cs(s1, 1))
-    og = OracleGrid(n, n)
-    ref = og.mf_solve(eps=1e-8, max_iterations=10 ** 5)
-    assert rt.iterations == ref.iterations
-    assert abs(rt.r_norm2 - ref.r_norm) / ref.initial_r_norm <= 1e-12
+    if n <= 514:                                                   # (the serial oracle needs 25 s at N = 1026; the single-GPU solve it
+        og = OracleGrid(n, n)                                      #  is compared with there is pinned by test_gpu_parity.py)
+        ref = og.mf_solve(eps=1e-8, max_iterations=10 ** 5)
+        assert rt.iterations == ref.iterations
+        assert abs(rt.r_norm2 - ref.r_norm) / ref.initial_r_norm <= 1e-12
     t.close()
 
 
