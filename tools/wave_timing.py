@@ -48,3 +48,33 @@ for k, name in enumerate(("stencil", "update")):
     print("   main loop (us) by XCD (block % 8):", " ".join(f"{dur[(idx // 4) % 8 == x].mean():5.1f}" for x in range(8)))
     print("   main loop (us) by wave in block  :", " ".join(f"{dur[idx % 4 == x].mean():5.1f}" for x in range(4)))
     print("   main loop (us) by item % 32      :", " ".join(f"{dur[idx % 32 == x].mean():5.1f}" for x in range(32)))
+
+# Are the slow waves the same ones from launch to launch?  Correlate per-workgroup main-loop durations between the two kernels
+# of this dump and with a second, independent solve (another launch of each kernel).
+def per_block(dd):
+    out = []
+    for k in range(2):
+        w = dd[k]
+        ok = w[:, 5] > 0
+        dur = np.where(ok, (w[:, 5] - w[:, 4]) / 100.0, np.nan)
+        nb = len(dur) // 4
+        out.append(np.nanmean(dur[:nb * 4].reshape(nb, 4), axis=1))
+    return out
+
+
+first = per_block(d)
+s._handle.solve(p)
+d2 = np.fromfile(OUT, dtype=np.uint64).reshape(2, -1, 6).astype(np.int64)
+second = per_block(d2)
+nb = int(np.sum(~np.isnan(first[0])))
+for name, a, b in (("stencil launch vs update launch (same solve)", first[0][:nb], first[1][:nb]),
+                   ("stencil launch vs stencil launch of another solve", first[0][:nb], second[0][:nb]),
+                   ("update launch vs update launch of another solve", first[1][:nb], second[1][:nb])):
+    m = ~np.isnan(a) & ~np.isnan(b)
+    # remove the XCD-parity component first: it is known and handled by the class split
+    par = np.arange(len(a)) % 8
+    a2, b2 = a.copy(), b.copy()
+    for x in range(8):
+        a2[par == x] -= np.nanmean(a[par == x]); b2[par == x] -= np.nanmean(b[par == x])
+    print(f"per-workgroup duration correlation, {name}: raw {np.corrcoef(a[m], b[m])[0, 1]:.3f}, XCD means removed {np.corrcoef(a2[m], b2[m])[0, 1]:.3f} "
+          f"(std {np.nanstd(a2):.2f} / {np.nanstd(b2):.2f} us)")
