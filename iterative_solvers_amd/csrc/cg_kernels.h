@@ -71,18 +71,23 @@ __host__ __device__ inline bool node_interior(const Geom& g, int x, int y) {
 // gc (2-D decomposition): bit 0 = the column left of the panel's first strip belongs to another part (a ghost
 // column of this part), bit 1 = the same on the right of its last strip.
 struct Panel { int y0, y1, s0, ns, ty, nchunks, item0, gc; };
-// XCD classes: on this part the even XCDs run the same work 6-11 % slower than the odd ones (per-wave timelines,
-// profiles/r02_wave_timing.txt), and workgroups land on XCD blockIdx % 8.  With ncls == 2 the items [cls0[0], cls0[1]) --
-// cut a few per cent shorter -- are served by the even-numbered workgroups only and the items [cls0[1], cls0[2]) by the odd
-// ones.  A wrong guess about the placement costs balance, never correctness.
-struct WorkList { Panel p[kMaxPanels]; int np; int nitems; int ncls; int cls0[3]; };
+// XCD classes: workgroups land on XCD blockIdx % 8, and every XCD has its own L2.  With ncls == 8 the items are cut into
+// eight contiguous ranges [cls0[k], cls0[k+1]) -- whole bands of chunk rows -- and range k is served by the workgroups with
+// blockIdx % 8 == k only: the strips left and right of a workgroup (whose edge columns it reads) and the chunk rows above and
+// below (whose halo rows it reads) are then work of the SAME XCD and those reads hit its L2 instead of going to the fabric
+// (PMC: read traffic of the stencil launch 1.10 x -> see profiles/r02_tune_notes.md).  A wrong guess about the placement costs
+// those hits, never correctness.
+constexpr int kXcds = 8;
+struct WorkList { Panel p[kMaxPanels]; int np; int nitems; int ncls; int cls0[kXcds + 1]; };
 // the item indices a wave takes: first, first + step, ... < end
 struct ItemSeq { int first, step, begin, end; };
 __device__ inline ItemSeq item_seq(const WorkList& wl, int wave) {
-    if (wl.ncls == 2) {
-        const int cls = blockIdx.x & 1, nb = (gridDim.x + 1 - cls) >> 1;
-        const int begin = cls ? wl.cls0[1] : wl.cls0[0], end = cls ? wl.cls0[2] : wl.cls0[1];
-        return ItemSeq{begin + (int)(blockIdx.x >> 1) * kWaves + wave, nb * kWaves, begin, end};
+    if (wl.ncls == kXcds) {
+        const int cls = blockIdx.x % kXcds, nb = (gridDim.x - cls + kXcds - 1) / kXcds;
+        int begin = wl.cls0[0], end = wl.cls0[1];
+#pragma unroll
+        for (int k = 1; k < kXcds; ++k) if (k == cls) { begin = wl.cls0[k]; end = wl.cls0[k + 1]; }     // constant indices only
+        return ItemSeq{begin + (int)(blockIdx.x / kXcds) * kWaves + wave, nb * kWaves, begin, end};
     }
     return ItemSeq{(int)blockIdx.x * kWaves + wave, (int)gridDim.x * kWaves, 0, wl.nitems};
 }

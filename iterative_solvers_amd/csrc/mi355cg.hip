@@ -213,32 +213,20 @@ Plan make_plan(const std::vector<Rect>& rects, int max_rows, int fixed_ty = 0) {
     WorkList dry{};
     for (auto& r : rects) strip_rows += add_panel(dry, r.y0, r.y1, r.s0, r.s1, 0, 0);
     if (strip_rows == 0) return pl;
-    // XCD skew: the even XCDs are the slower ones (see WorkList); their items are cut `skew` per cent shorter.  Only for
-    // launches that fill the chip, and never for the single-row edge launches.
-    const int skew = std::max(0, std::min(30, env_int("MI355CG_XCD_SKEW", 5)));
-    const bool classes = skew > 0 && fixed_ty == 0 && max_blocks >= 2 && strip_rows >= 4LL * waves && (int)rects.size() * 2 <= kMaxPanels;
+    // XCD classes (see WorkList): only for launches that fill the chip, never for the single-row edge launches
+    const bool classes = env_int("MI355CG_XCD_CLASSES", 1) != 0 && fixed_ty == 0 && max_blocks >= kXcds && strip_rows >= 4LL * waves;
     auto build = [&](int ty) {
         WorkList wl{};
         wl.ncls = 1;
-        if (!classes) { for (auto& r : rects) add_panel(wl, r.y0, r.y1, r.s0, r.s1, ty, r.gc); return wl; }
-        wl.ncls = 2;
-        for (int k = 0; k < 2; ++k) {
-            wl.cls0[k] = wl.nitems;
-            for (auto& r : rects) {
-                const int R = r.y1 - r.y0 + 1;
-                if (R < 4) { if (k == 1) add_panel(wl, r.y0, r.y1, r.s0, r.s1, ty, r.gc); continue; }
-                // both classes get the same number of chunk rows of this rectangle; the even-XCD ones are shorter
-                const int nch = std::max(1, ((R + ty - 1) / ty + 1) / 2);
-                const int Re = std::max(1, std::min(R - 1, (int)((long long)R * (100 - skew) / (200 - skew))));
-                const int ya = k == 0 ? r.y0 : r.y0 + Re, yb = k == 0 ? r.y0 + Re - 1 : r.y1;
-                add_panel(wl, ya, yb, r.s0, r.s1, std::max(1, (yb - ya + 1 + nch - 1) / nch), r.gc);
-            }
+        for (auto& r : rects) add_panel(wl, r.y0, r.y1, r.s0, r.s1, ty, r.gc);
+        if (classes) {
+            wl.ncls = kXcds;
+            for (int k = 0; k <= kXcds; ++k) wl.cls0[k] = (int)((long long)wl.nitems * k / kXcds);
         }
-        wl.cls0[2] = wl.nitems;
         return wl;
     };
     auto fits = [&](const WorkList& wl, long long rounds) {
-        if (wl.ncls == 2) return wl.cls0[1] - wl.cls0[0] <= rounds * (waves / 2) && wl.cls0[2] - wl.cls0[1] <= rounds * (waves / 2);
+        if (wl.ncls == kXcds) { for (int k = 0; k < kXcds; ++k) if (wl.cls0[k + 1] - wl.cls0[k] > rounds * (waves / kXcds)) return false; return true; }
         return wl.nitems <= rounds * waves;
     };
     int ty = fixed_ty;
@@ -255,7 +243,7 @@ Plan make_plan(const std::vector<Rect>& rects, int max_rows, int fixed_ty = 0) {
     }
     pl.ty = ty;
     pl.grid = std::max(1, std::min(max_blocks, (pl.wl.nitems + kWaves - 1) / kWaves));
-    if (pl.wl.ncls == 2) pl.grid = std::min(max_blocks & ~1, (pl.grid + 1) & ~1);      // the two classes alternate over the workgroups
+    if (pl.wl.ncls == kXcds) pl.grid = std::min(max_blocks / kXcds * kXcds, (pl.grid + kXcds - 1) / kXcds * kXcds);      // the classes take turns over the workgroups
     return pl;
 }
 constexpr int kMaxRowsF64 = 800, kMaxRowsF32 = 64;

@@ -17,8 +17,8 @@ VARIANTS = [
     {"MI355CG_DEPTH": "3", "MI355CG_ITEM_ROWS": "1"},
     {"MI355CG_BLOCKS": "37"},
     {"MI355CG_WAVES": "256", "MI355CG_ITEM_ROWS": "5"},
-    {"MI355CG_XCD_SKEW": "0"},                              # no even/odd-XCD classes
-    {"MI355CG_XCD_SKEW": "25", "MI355CG_ITEM_ROWS": "9"},
+    {"MI355CG_XCD_CLASSES": "0"},                           # items dealt to all workgroups alike (no per-XCD ranges)
+    {"MI355CG_BLOCKS": "100", "MI355CG_ITEM_ROWS": "9"},    # grid not a multiple of 8 XCD classes -> rounded down to 96
 ]
 
 
