@@ -13,7 +13,7 @@ RHS (the reference's f and Dirichlet data), x0 = 0, convergence tests disabled s
 
 Prints ONE JSON line (rank 0).  `value` = CG iterations/s of the whole job (weak scaling: in units of config-2-sized
 parts advanced per second), timed on the host around K iterations between device synchronisations; `hbm_gbps` = bytes the
-iteration really moves (60 B per unknown for the REL_2NORM loop) per second; the per-kernel roofline comes from HIP events.
+iteration really moves (58 B per unknown for the REL_2NORM loop) per second; the per-kernel roofline comes from HIP events.
 """
 from __future__ import annotations
 
@@ -30,9 +30,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured-achievable (float4 copy, guide)
 SURVEY_BYTES_PER_UNKNOWN = 88.0  # SURVEY 8d's convention: 11 words per unknown per iteration (textbook three-phase CG)
 # Compulsory words per unknown and launch of THIS implementation -- what roofline.achieved counts.
-# REL_2NORM: stencil launch reads r, p and writes p = 3; update launch reads p, r and writes r = 3 on odd iterations,
-# reads p, p_prev, r, x and writes r, x = 6 on even ones: 4.5 on average, 7.5 per iteration.  MSG: 3 + 5 (x every iteration).
-WORDS = {"rel2": {"stencil": 3, "update": 4.5}, "msg": {"stencil": 3, "update": 5}}
+# REL_2NORM: stencil launch reads r, p and writes p = 3; update launch reads p, r and writes r = 3 on three iterations out of M = 4
+# and reads p, r, x, three older directions and writes r, x = 8 on the fourth: 4.25 on average, 7.25 per iteration
+# (MI355CG_XSTEPS=2: 3 and 6 alternating = 4.5, 7.5 per iteration).  MSG: 3 + 5 (x every iteration).
+_M = 2 if os.environ.get("MI355CG_XSTEPS") == "2" else 4
+WORDS = {"rel2": {"stencil": 3, "update": (3 * (_M - 1) + (4 + _M)) / _M}, "msg": {"stencil": 3, "update": 5}}
 
 
 def unknowns(n: int) -> int:

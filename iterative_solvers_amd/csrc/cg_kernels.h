@@ -102,6 +102,7 @@ struct CgState {
     double rnorm2;      // ||r||_2
     double rmax, dmax, emax, d2, e2;
     int it, done, reason, converged, first, pad_;
+    double alpha_hist[4];   // step length of iteration k at [k & 3]: the folded x update (XM >= 2) applies up to three earlier steps at once
 };
 struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2, tr2; };   // tr2: ||b - A x||_2^2 (REL_2NORM diagnostics mode, written by k_resid2_hist)
 
@@ -818,7 +819,8 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
                 if (a.init == 2) {
                     if (s.done) o->rr = s.rr_prev;
                     o->done = 0; o->reason = 0; o->converged = 0; o->alpha = 0.0; o->r0norm = a.r0norm_resume;
-                } else { o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; }
+                    for (int i = 0; i < 4; ++i) o->alpha_hist[i] = 0.0;
+                } else { o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; o->alpha_hist[(s.it + 1) & 3] = alpha_d; }
             }
         }
     }
@@ -831,16 +833,17 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
 // (Ap, p).  A p never touches HBM.  XM selects what happens to x in this launch:
 //   0  nothing (odd iterations of the two-step scheme below);
 //   1  x += alpha p plus the norms |dx|, |x - u| (MSG rule every iteration; REL_2NORM with per-iteration diagnostics);
-//   2  two-step update on even iterations k: x = (x + alpha_{k-1} p_{k-1}) + alpha_k p_k.  p_{k-1} is still intact in the
-//      other direction buffer, alpha_{k-1} is in the state.  Same operations in the same order as two single updates,
-//      but x is read and written once per two iterations: 7.5 words per unknown and iteration on average
-//      (stencil launch 3: r, p in, p out; this launch 3 on odd iterations, 6 on even ones).
+//   M = 2 or 4  folded update on iterations k = 0 mod M: x = (..(x + alpha_{k-M+1} p_{k-M+1}) + ..) + alpha_k p_k.  The M - 1 earlier
+//      directions are still intact in the other buffers of the direction ring, their step lengths are in the state
+//      (alpha_hist).  Same operations in the same order as M single updates, but x is read and written once per M iterations:
+//      M = 4: stencil launch 3 words (r, p in, p out); this launch 3 words on three iterations and 8 on the fourth
+//      (p, r, x, three old directions in; r, x out): 7.25 words per unknown and iteration on average (M = 2: 7.5).
 template <typename T>
 struct UpdateStArgs {
     Geom g;
     WorkList wl;
     const T* p;          // current direction, ghost rows / columns valid
-    const T* pprev;      // XM == 2: the previous direction (the other ping-pong buffer)
+    const T* pprev[3];   // XM >= 2: the directions of the 1, 2, 3 iterations before (the other buffers of the ring)
     T* r; T* x; const T* u;
     const double* partA; int nA, strideA, esA;
     double* partB; int strideB, slotB;
@@ -861,20 +864,23 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     const ItemSeq seq = item_seq(a.wl, wave);
     MI355CG_WT_BEGIN
     constexpr bool FULL = XM == 1;
-    struct Raw { vec_t p, r, x, u, pp; T pe; };
+    constexpr int NP = XM >= 2 ? XM - 1 : 0;          // earlier directions folded into this launch's x update
+    struct Raw { vec_t p, r, x, u, pp[NP > 0 ? NP : 1]; T pe; };
 
     // ---- fetch cursor (see k_stencil) ----
     int f_item = seq.first;
     bool f_have = f_item < seq.end;
     ItemAddr F{};
     int f_idx = 0, f_so = 0, f_y = 0;
-    rsrc_t rs_p = make_rsrc(a.p), rs_r = rs_p, rs_x = rs_p, rs_pp = rs_p, rs_u = rs_p;
+    rsrc_t rs_p = make_rsrc(a.p), rs_r = rs_p, rs_x = rs_p, rs_u = rs_p;
+    rsrc_t rs_pp[NP > 0 ? NP : 1] = {rs_p};
     auto enter = [&](int idx) {
         F = item_addr<T, VEC, DESC>(g, decode_item(a.wl, a.reverse ? seq.end - 1 - (idx - seq.begin) : idx), lane);   // reversed within the wave's class
         rs_p = make_rsrc(a.p + F.base_el);
         rs_r = make_rsrc(a.r + F.base_el);
         rs_x = make_rsrc(XM != 0 ? a.x + F.base_el : a.p + F.base_el);
-        rs_pp = make_rsrc(XM == 2 ? a.pprev + F.base_el : a.p + F.base_el);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) rs_pp[i] = make_rsrc(a.pprev[i] + F.base_el);
         rs_u = make_rsrc((FULL && HAS_U) ? a.u + F.base_el : a.p + F.base_el);
         f_idx = -1; f_so = F.so_first; f_y = DESC ? F.ystart + 1 : F.ystart - 1;
     };
@@ -892,7 +898,8 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
         w.p = buf_load<vec_t>(rs_p, vo, f_so);
         w.r = buf_load<vec_t>(rs_r, vown, f_so);
         if (XM != 0) w.x = buf_load<vec_t>(rs_x, vown, f_so);
-        if (XM == 2) w.pp = buf_load<vec_t>(rs_pp, vown, f_so);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) w.pp[i] = buf_load<vec_t>(rs_pp[i], vown, f_so);
         if (FULL && HAS_U) w.u = buf_load<vec_t>(rs_u, vown, f_so);
         w.pe = buf_load<T>(rs_p, own ? F.ve_own : kOob, f_so);
         if (DESC) { f_so -= row_step<T>(g, f_y - 1); --f_y; } else { f_so += row_step<T>(g, f_y); ++f_y; }
@@ -942,14 +949,16 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     }
     const T alpha = (T)alpha_d;
     MI355CG_WT_MID
-    const T alpha_prev = (T)s.alpha;       // XM == 2: step length of the previous iteration (0 after init / resume)
+    T aprev[NP > 0 ? NP : 1] = {(T)0};     // XM >= 2: step lengths of iterations k-1, k-2, k-3 (k = s.it + 1; 0 after init / resume)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) aprev[i] = (T)scalar_load(&a.s_in->alpha_hist[(s.it - i) & 3]);
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
     double s_rmax = 0, s_dmax = 0, s_emax = 0;
     vec_t p_b;
     Raw c;                                 // centre row
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { p_b[j] = (T)0; c.p[j] = (T)0; c.r[j] = (T)0; c.x[j] = (T)0; c.u[j] = (T)0; c.pp[j] = (T)0; }
+    for (int j = 0; j < VEC; ++j) { p_b[j] = (T)0; c.p[j] = (T)0; c.r[j] = (T)0; c.x[j] = (T)0; c.u[j] = (T)0; for (int i = 0; i < (NP > 0 ? NP : 1); ++i) c.pp[i][j] = (T)0; }
     c.pe = (T)0;
 
     while (c_have) {
@@ -985,7 +994,12 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                         const double rd = (double)rn[j];
                         dd_acc_prod(s_rr, rd, rd);
                         s_rmax = fmax(s_rmax, fabs(rd));
-                        if (XM == 2) xn[j] = (c.x[j] + alpha_prev * c.pp[j]) + alpha * cc;   // two x = x + alpha*z steps
+                        if (XM >= 2) {                                   // M single x = x + alpha*z steps, oldest first
+                            T t = c.x[j];
+#pragma unroll
+                            for (int i = NP - 1; i >= 0; --i) t = t + aprev[i] * c.pp[i][j];
+                            xn[j] = t + alpha * cc;
+                        }
                         if (FULL) {
                             xn[j] = c.x[j] + alpha * cc;                 // x = x + alpha*z        msg_solver.cpp:105-107
                             const double dx = (double)(xn[j] - c.x[j]);  // diff = x - x_prev      msg_solver.cpp:124-127
@@ -1028,7 +1042,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
         if (blockIdx.x == 0) {
             copy_state(a.s_out, a.s_in);
             CgState* o = a.s_out;
-            o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz;
+            o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; o->alpha_hist[(s.it + 1) & 3] = alpha_d;
         }
     }
     arrive_and_record(1, a.partB, a.strideB, a.rec, lds);
@@ -1051,9 +1065,11 @@ __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
     if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, a.s_in, s, d);
 }
 
-// x += alpha * p over the part's own cells (work items): the x update still pending when the two-step loop ends on an odd count.
+// The x updates still pending when the folded loop ends on a count that is not a multiple of M (up to three): over the
+// part's own cells, x = ((x + a[0] p[0]) + a[1] p[1]) + a[2] p[2], oldest step first.
+template <typename T> struct FlushArgs { const T* p[3]; T a[3]; int n; };
 template <typename T, int VEC>
-__global__ __launch_bounds__(kBlock) void k_flush_x(const Geom g, const WorkList wl, T* x, const T* p, T alpha) {
+__global__ __launch_bounds__(kBlock) void k_flush_x(const Geom g, const WorkList wl, T* x, const FlushArgs<T> f) {
     typedef typename VecOf<T, VEC>::type vec_t;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -1063,10 +1079,13 @@ __global__ __launch_bounds__(kBlock) void k_flush_x(const Geom g, const WorkList
         if (x0 < (it.ya <= g.half ? g.cb : 0) || x0 >= g.xlim) continue;
         for (int y = it.ya; y <= it.yb; ++y) {
             const long long off = row_off(g, y) - g.base0 + x0;
-            const vec_t xv = *reinterpret_cast<const vec_t*>(x + off), pv = *reinterpret_cast<const vec_t*>(p + off);
-            vec_t xn;
+            vec_t xn = *reinterpret_cast<const vec_t*>(x + off);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) xn[j] = xv[j] + alpha * pv[j];           // x = x + alpha*z
+            for (int k = 0; k < 3; ++k) if (k < f.n) {
+                const vec_t pv = *reinterpret_cast<const vec_t*>(f.p[k] + off);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) xn[j] = xn[j] + f.a[k] * pv[j];          // x = x + alpha*z
+            }
             *reinterpret_cast<vec_t*>(x + off) = xn;
         }
     }

@@ -44,6 +44,7 @@ int env_int(const char* name, int dflt) {
 inline long long round_up(long long v, long long m) { return (v + m - 1) / m * m; }
 
 constexpr int kRecHeader = kRecWords;     // doubles reserved for the sums (hi/lo pairs) and maxes at the head of a part's record
+constexpr int kRing = 4;           // direction buffers of a context (ring; M = xsteps of them are in use)
 constexpr int kStripCols = 128;    // fp64 strip = 64 lanes x double2: the unit of the x-cuts of a 2-D decomposition
 
 struct EventPool {
@@ -80,9 +81,10 @@ struct mi355cg_ctx {
     int strideA = 0, strideB = 0;
 
     // device vectors in storage layout (fp64 set always; fp32 set for F32_MIXED)
-    double *x = nullptr, *r = nullptr, *p[2] = {nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
+    double *x = nullptr, *r = nullptr, *p[kRing] = {nullptr, nullptr, nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
+    int xsteps = 4;                     // M: the direction ring has M buffers, x is touched every M-th iteration (env MI355CG_XSTEPS: 2 | 4)
     double* scratch[2] = {nullptr, nullptr};      // mi355cg_apply / true residual work space, allocated on first use: never a solver vector
-    float *xf = nullptr, *rf = nullptr, *pf[2] = {nullptr, nullptr}, *apf = nullptr;
+    float *xf = nullptr, *rf = nullptr, *pf[kRing] = {nullptr, nullptr, nullptr, nullptr}, *apf = nullptr;
     double* packed = nullptr;           // device scratch, pk_len doubles
     double *partA = nullptr, *partB = nullptr, *partR = nullptr;
     double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's record = reduced partials [+ its two boundary rows] (feeds the all-gather)
@@ -104,7 +106,7 @@ struct mi355cg_ctx {
     long long csr_n = 0, csr_nnz = 0;
     int *csr_row_map = nullptr, *csr_entries = nullptr; double* csr_values = nullptr;
     int grid_csr = 0, grid_update = 0;
-    int cur = 0;                        // p[cur] holds the current direction after the last stencil
+    int cur = 0;                        // p[cur] holds the current direction after the last stencil: cur = (iterations done) % xsteps
     int nA_dist = 0;                    // slab mode: stencil partial slots written by the last stencil phase
 
     // hipGraph cache for launch-bound (small) grids: one instantiated graph per distinct chunk shape of a solve
@@ -323,11 +325,11 @@ struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool x2 = false; };
 
 // Phase A'.  Does NOT flip c->cur (a part's interior and edge launches share one direction pair).
 template <typename T, int VEC>
-void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[2], const Where& w, const PartSrc& pb, const RecSpec* rec = nullptr) {
+void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[kRing], const Where& w, const PartSrc& pb, const RecSpec* rec = nullptr) {
     if (w.plan->wl.nitems == 0) return;
     StencilArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
-    a.r = r; a.pin = p[c->cur]; a.pout = p[c->cur ^ 1]; a.ap = nullptr;
+    a.r = r; a.pin = p[c->cur]; a.pout = p[(c->cur + 1) % c->xsteps]; a.ap = nullptr;
     a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
     a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slot;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
@@ -348,11 +350,12 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
 // Phase B on the stencil's work items, marched the other way (it starts on what the stencil launch touched last).
 // c->cur was flipped after this iteration's stencil launch: it is the iteration number's parity.
 template <typename T, int VEC>
-void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* const p[2], const T* u, const Where& w, const PartSrc& pa, const RecSpec* rec = nullptr) {
+void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* const p[kRing], const T* u, const Where& w, const PartSrc& pa, const RecSpec* rec = nullptr) {
     if (w.plan->wl.nitems == 0) return;
     UpdateStArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
-    a.p = p[c->cur]; a.pprev = p[c->cur ^ 1]; a.r = r; a.x = x; a.u = u;
+    a.p = p[c->cur]; a.r = r; a.x = x; a.u = u;
+    for (int i = 0; i < 3; ++i) a.pprev[i] = p[(c->cur + 2 * c->xsteps - 1 - i) % c->xsteps];      // directions of iterations k-1, k-2, k-3
     a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
     a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slot;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
@@ -361,7 +364,9 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
     const bool d3 = c->depth == 3;
 #define MI355CG_UST(XM, HASU) do { if (d3) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 3, true>), grid, block, 0, w.stream, a); \
                                    else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, true>), grid, block, 0, w.stream, a); } while (0)
-    if (cfg.x2) { if (c->cur == 0) MI355CG_UST(2, false); else MI355CG_UST(0, false); }      // even iterations carry both x steps
+    if (cfg.x2) {                    // iterations k = 0 mod M carry all M x steps (c->cur = k % M)
+        if (c->cur != 0) MI355CG_UST(0, false); else if (c->xsteps == 4) MI355CG_UST(4, false); else MI355CG_UST(2, false);
+    }
     else if constexpr (VEC == 2) { if (cfg.has_u) MI355CG_UST(1, true); else MI355CG_UST(1, false); }
 #undef MI355CG_UST
 }
@@ -381,11 +386,16 @@ void launch_update_flat(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, const T*
     else hipLaunchKernelGGL((k_update<T, VEC, false>), dim3(grid), dim3(kBlock), 0, stream, a);
 }
 
+// The x steps of the iterations after the last multiple of M (REL_2NORM folded update), oldest first.
 template <typename T, int VEC>
-void launch_flush_x(const mi355cg_ctx* c, const Plan& plan, T* x, const T* p, T alpha, hipStream_t stream) {
-    if (plan.wl.nitems == 0) return;
+void launch_flush_x(const mi355cg_ctx* c, const Plan& plan, T* x, T* const p[kRing], const CgState& fin, hipStream_t stream) {
+    const int pending = fin.it % c->xsteps;
+    if (plan.wl.nitems == 0 || pending == 0) return;
+    FlushArgs<T> f{};
+    f.n = pending;
+    for (int j = 0; j < pending; ++j) { const int k = fin.it - pending + 1 + j; f.p[j] = p[k % c->xsteps]; f.a[j] = (T)fin.alpha_hist[k & 3]; }
     hipLaunchKernelGGL((k_flush_x<T, VEC>), dim3(std::max(1, std::min(1024, (plan.wl.nitems + kWaves - 1) / kWaves))), dim3(kBlock), 0, stream,
-                       kernel_geom<T, VEC>(c), plan.wl, x, p, alpha);
+                       kernel_geom<T, VEC>(c), plan.wl, x, f);
 }
 
 void launch_check(mi355cg_ctx* c, const IterCfg& cfg, hipStream_t stream, const PartSrc& pb) {
@@ -628,8 +638,7 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
     HIPCK(hipMemsetAsync(c->xf, 0, bytes, c->stream));
     int done_its = 0;
     if (resume_r0norm < 0.0) {
-        HIPCK(hipMemsetAsync(c->pf[0], 0, bytes, c->stream));
-        HIPCK(hipMemsetAsync(c->pf[1], 0, bytes, c->stream));
+        for (int k = 0; k < c->xsteps; ++k) HIPCK(hipMemsetAsync(c->pf[k], 0, bytes, c->stream));
         HIPCK(hipMemsetAsync(c->apf, 0, bytes, c->stream));
         c->cur = 0;
         launch_update_flat<float, 4>(c, cfg, c->xf, c->rf, c->pf[0], c->apf, (const float*)nullptr, c->stream, c->whole32.grid);
@@ -646,7 +655,7 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
             hipEvent_t e0 = nullptr;
             prof_begin(c, &e0);
             launch_iteration_stencil<float, 4>(c, cfg, c->rf, c->pf, w, own_partB(c));
-            c->cur ^= 1;
+            c->cur = (c->cur + 1) % c->xsteps;
             prof_end(c, 0, e0);
             prof_begin(c, &e0);
             launch_iteration_update<float, 4>(c, cfg, c->xf, c->rf, c->pf, (const float*)nullptr, w, pA);
@@ -657,11 +666,9 @@ int inner_cg_f32(mi355cg_ctx* c, const IterCfg& cfg, int sync_every, const volat
         done_its = c->summary_h->it;
     }
     *its = c->summary_h->it;
-    c->cur = *its & 1;
-    if (*its > 0 && (*its & 1)) {        // two-step scheme: after an odd count the last x += alpha*p is still pending
-        launch_flush_x<float, 4>(c, c->whole32, c->xf, c->pf[c->cur], (float)c->summary_h->alpha, c->stream);
-        HIPCK(hipGetLastError());
-    }
+    c->cur = *its % c->xsteps;
+    launch_flush_x<float, 4>(c, c->whole32, c->xf, c->pf, *c->summary_h, c->stream);      // x steps still pending after the last multiple of M
+    HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
 
@@ -777,11 +784,14 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "hipStreamCreate failed"); return cleanup(); }
     const long long L = c->storage_len;
-    double** vecs[] = {&c->x, &c->r, &c->p[0], &c->p[1], &c->ap, &c->b, &c->u};
-    for (auto v : vecs) if ((rc = alloc_vec(v, L))) return cleanup();
+    c->xsteps = env_int("MI355CG_XSTEPS", 4) == 2 ? 2 : 4;
+    double** vecs[] = {&c->x, &c->r, &c->p[0], &c->p[1], &c->ap, &c->b, &c->u, &c->p[2], &c->p[3]};
+    for (int k = 0; k < 7 + (c->xsteps - 2); ++k) if ((rc = alloc_vec(vecs[k], L))) return cleanup();
     if (dtype == MI355CG_F32_MIXED) {
-        float** fv[] = {&c->xf, &c->rf, &c->pf[0], &c->pf[1], &c->apf};
-        for (auto v : fv) {
+        float** fv[] = {&c->xf, &c->rf, &c->pf[0], &c->pf[1], &c->apf, &c->pf[2], &c->pf[3]};
+        const int nfv = 5 + (c->xsteps - 2);
+        for (int k = 0; k < nfv; ++k) {
+            float** v = fv[k];
             if (hipMalloc((void**)v, sizeof(float) * L) != hipSuccess || hipMemset(*v, 0, sizeof(float) * L) != hipSuccess) {
                 rc = fail(MI355CG_ERR_HIP, "fp32 vector allocation failed"); return cleanup();
             }
@@ -911,7 +921,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf, c->pf[0], c->pf[1], c->apf,
+    void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->p[2], c->p[3], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf, c->pf[0], c->pf[1], c->pf[2], c->pf[3], c->apf,
                    c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist, c->ticket};
     for (void* p : dev) if (p) hipFree(p);
     if (c->csr_row_map) hipFree(c->csr_row_map);
@@ -1043,8 +1053,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     // x = 0, r = b, z = 0 (the first stencil makes z = r + 0*z = r)    msg_solver.cpp:33-39
     const size_t bytes = sizeof(double) * c->storage_len;
     HIPCK(hipMemsetAsync(c->x, 0, bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->p[0], 0, bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->p[1], 0, bytes, c->stream));
+    for (int k = 0; k < c->xsteps; ++k) HIPCK(hipMemsetAsync(c->p[k], 0, bytes, c->stream));
     HIPCK(hipMemsetAsync(c->ap, 0, bytes, c->stream));
     HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
     c->cur = 0;
@@ -1091,7 +1100,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
                 hipEvent_t e0 = nullptr;
                 prof_begin(c, &e0);
                 launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), own_partB(c));
-                c->cur ^= 1;
+                c->cur = (c->cur + 1) % c->xsteps;
                 prof_end(c, 0, e0);
                 prof_begin(c, &e0);
                 IterCfg ucfg = cfg;
@@ -1108,7 +1117,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
             }
             return MI355CG_OK;
         };
-        if (graph_ok && m >= 8 && (m % 2) == 0) {
+        if (graph_ok && m >= 8) {
             // Launch-bound grids: replay the chunk as one hipGraph.  The chunk's kernel arguments depend only on
             // (m, direction-buffer parity, which iterations read u), so equal shapes share an instantiated graph.
             std::vector<char> flags(m);
@@ -1129,7 +1138,8 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
                 c->graphs.push_back({m, cur0, flags, exec});
                 hit = &c->graphs.back();
             }
-            HIPCK(hipGraphLaunch(hit->exec, c->stream));          // m is even: the parity of c->cur is unchanged
+            HIPCK(hipGraphLaunch(hit->exec, c->stream));
+            c->cur = (c->cur + m) % c->xsteps;                    // what enqueue_chunk would have left behind
         } else {
             if (int rc = enqueue_chunk()) return rc;
         }
@@ -1152,9 +1162,9 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     CgState fin = *c->summary_h;
     // Launches enqueued after the stop decision return in their prologue but still flipped c->cur on the
     // host: the direction of the last REAL iteration is p[it % 2] (the solve starts with cur = 0).
-    c->cur = fin.it & 1;
-    if (cfg.x2 && fin.it > 0 && (fin.it & 1)) {      // two-step scheme: after an odd count the last x += alpha*p is still pending
-        launch_flush_x<double, 2>(c, c->whole, c->x, c->p[c->cur], fin.alpha, c->stream);
+    c->cur = fin.it % c->xsteps;
+    if (cfg.x2) {                                   // folded x update: the steps after the last multiple of M are still pending
+        launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, c->stream);
         HIPCK(hipGetLastError());
         HIPCK(hipStreamSynchronize(c->stream));
     }
@@ -1330,8 +1340,7 @@ int mi355cg_dist_begin(mi355cg_handle c, const mi355cg_params* prm, void* stream
     hipStream_t st = pick_stream(c, stream);
     const size_t bytes = sizeof(double) * c->storage_len;
     HIPCK(hipMemsetAsync(c->x, 0, bytes, st));
-    HIPCK(hipMemsetAsync(c->p[0], 0, bytes, st));
-    HIPCK(hipMemsetAsync(c->p[1], 0, bytes, st));
+    for (int k = 0; k < c->xsteps; ++k) HIPCK(hipMemsetAsync(c->p[k], 0, bytes, st));
     HIPCK(hipMemsetAsync(c->ap, 0, bytes, st));
     HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, st));
     c->cur = 0;
@@ -1416,7 +1425,7 @@ int mi355cg_dist_stencil(mi355cg_handle c, const double* gathered_B, int nranks,
 }
 int mi355cg_dist_flip(mi355cg_handle c) {
     if (!c) return fail(MI355CG_ERR_INVALID, "null handle");
-    c->cur ^= 1;
+    c->cur = (c->cur + 1) % c->xsteps;
     return MI355CG_OK;
 }
 // rows: as in mi355cg_dist_stencil.  The update rebuilds A p from the stored direction, so its first and last owned row
@@ -1452,9 +1461,9 @@ int mi355cg_dist_finish(mi355cg_handle c, void* stream) {
     if (!c || !c->dist_active) return fail(MI355CG_ERR_STATE, "mi355cg_dist_begin has not run");
     const IterCfg cfg = make_cfg(&c->dist_prm);
     const CgState fin = *c->summary_h;
-    c->cur = fin.it & 1;                 // launches after the stop decision were no-ops but flipped the host-side index
-    if (cfg.x2 && fin.it > 0 && (fin.it & 1)) {
-        launch_flush_x<double, 2>(c, c->whole, c->x, c->p[c->cur], fin.alpha, pick_stream(c, stream));
+    c->cur = fin.it % c->xsteps;         // launches after the stop decision were no-ops but advanced the host-side index
+    if (cfg.x2) {
+        launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, pick_stream(c, stream));
         HIPCK(hipGetLastError());
     }
     return MI355CG_OK;

@@ -420,8 +420,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         c->profiling = t->profiling;
         const size_t bytes = sizeof(double) * c->storage_len;
         HIPCK(hipMemsetAsync(c->x, 0, bytes, c->stream));
-        HIPCK(hipMemsetAsync(c->p[0], 0, bytes, c->stream));
-        HIPCK(hipMemsetAsync(c->p[1], 0, bytes, c->stream));
+        for (int k = 0; k < c->xsteps; ++k) HIPCK(hipMemsetAsync(c->p[k], 0, bytes, c->stream));
         HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
         c->cur = 0;
         launch_update_flat<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, c->stream, c->whole.grid);
@@ -490,7 +489,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
                     launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), gsrc(p, 1), &rs);
                 }
                 prof_end(c, 0, e0);
-                c->cur ^= 1;
+                c->cur = (c->cur + 1) % c->xsteps;
                 if (!t->rccl) HIPCK(hipEventRecord(p.ev_recA, c->stream));
             }
             if (int rc = team_exchange_records(t, 0)) return rc;
@@ -537,8 +536,8 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
         HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));           // the last halo exchange writes this part's ghost cells
-        c->cur = fin.it & 1;
-        if (cfg.x2 && fin.it > 0 && (fin.it & 1)) launch_flush_x<double, 2>(c, c->whole, c->x, c->p[c->cur], fin.alpha, c->stream);
+        c->cur = fin.it % c->xsteps;
+        if (cfg.x2) launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, c->stream);
         HIPCK(hipGetLastError());
     }
     for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); HIPCK(hipStreamSynchronize(p.c->stream)); HIPCK(hipStreamSynchronize(p.comm)); }

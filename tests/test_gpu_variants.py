@@ -17,6 +17,7 @@ VARIANTS = [
     {"MI355CG_DEPTH": "3", "MI355CG_ITEM_ROWS": "1"},
     {"MI355CG_BLOCKS": "37"},
     {"MI355CG_WAVES": "256", "MI355CG_ITEM_ROWS": "5"},
+    {"MI355CG_XSTEPS": "2"},                                # x folded every 2nd iteration instead of every 4th (round 1's scheme)
     {"MI355CG_XCD_CLASSES": "0"},                           # items dealt to all workgroups alike (no per-XCD ranges)
     {"MI355CG_BLOCKS": "100", "MI355CG_ITEM_ROWS": "9"},    # grid not a multiple of 8 XCD classes -> rounded down to 96
 ]
@@ -66,7 +67,7 @@ def test_launch_shapes_take_identical_steps(n, rule_name):
         assert np.array_equal(x, ref[1]), env
 
 
-@pytest.mark.parametrize("stop_at", [1, 2, 7, 8])
+@pytest.mark.parametrize("stop_at", [1, 2, 3, 4, 5, 7, 8, 10])
 def test_two_step_x_update_is_flushed_for_odd_and_even_counts(stop_at):
     """x after exactly k iterations (k odd: one update still pending when the loop ends; k even: none)."""
     from iterative_solvers_amd import _capi

@@ -29,7 +29,7 @@ def run(name, n, dtype, rule, **kw):
     r = h.true_residual()                                    # A x - b in fp64
     b = h.rhs()
     wb = 4.0 if dtype == isa.F32_MIXED else 8.0
-    words = 8.0 if rule == 0 else 7.5                        # words really moved per unknown and iteration
+    words = 8.0 if rule == 0 else (7.5 if os.environ.get('MI355CG_XSTEPS') == '2' else 7.25)     # words really moved per unknown and iteration
     out = {"config": name, "n": n, "unknowns": U(n), "dtype": "f32-mixed" if dtype == isa.F32_MIXED else "f64",
            "rule": "msg" if rule == 0 else "rel2", "iterations": res.iterations, "converged": bool(res.converged),
            "stop_reason": res.stop_reason, "seconds": round(dt, 4), "iters_per_sec": round(res.iterations / dt, 1),

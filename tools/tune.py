@@ -20,7 +20,7 @@ ITERS = int(pos[1]) if len(pos) > 1 else 400
 F32 = len(pos) > 2 and pos[2] == "f32"
 U = (N // 2 - 1) * (3 * N // 2 - 1)
 WB = 4 if F32 else 8
-KNOBS = ("MI355CG_ITEM_ROWS", "MI355CG_WAVES", "MI355CG_BLOCKS", "MI355CG_DEPTH", "MI355CG_GRAPH", "MI355CG_XCD_CLASSES")
+KNOBS = ("MI355CG_XSTEPS", "MI355CG_ITEM_ROWS", "MI355CG_WAVES", "MI355CG_BLOCKS", "MI355CG_DEPTH", "MI355CG_GRAPH", "MI355CG_XCD_CLASSES")
 
 
 def measure(cfg):
@@ -45,5 +45,6 @@ def measure(cfg):
 for rep in range(2):
     for cfg in cfgs:
         its, ts, tu, lay = measure(cfg)
-        print(f"N={N} {'f32' if F32 else 'f64'} [{cfg:40s}] {its:8.1f} it/s = {7.5*WB*U*its/1e9:6.0f} GB/s moved | stencil {ts*1e3:8.1f} us ({3*WB*U/ts/1e6:5.0f} GB/s) "
-              f"update {tu*1e3:8.1f} us ({4.5*WB*U/tu/1e6:5.0f} GB/s) grid={lay['grid_stencil']} ty={lay['rows_per_item']}", flush=True)
+        wu = 4.5 if "MI355CG_XSTEPS=2" in cfg else 4.25            # words per unknown of the average update launch
+        print(f"N={N} {'f32' if F32 else 'f64'} [{cfg:40s}] {its:8.1f} it/s = {(3+wu)*WB*U*its/1e9:6.0f} GB/s moved | stencil {ts*1e3:8.1f} us ({3*WB*U/ts/1e6:5.0f} GB/s) "
+              f"update {tu*1e3:8.1f} us ({wu*WB*U/tu/1e6:5.0f} GB/s) grid={lay['grid_stencil']} ty={lay['rows_per_item']}", flush=True)
