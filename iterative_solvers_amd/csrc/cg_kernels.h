@@ -5,8 +5,8 @@
 //                           MatrixFreeSystem::apply (matrix_free_system.cpp:203-340) / KokkosSparse::spmv
 //                           (msg_solver.cpp:93), the direction update (matrix_free_system.cpp:436-438,
 //                           msg_solver.cpp:167-169) and the two dots (matrix_free_system.cpp:417, msg_solver.cpp:96,99).
-//   k_update_st (phase B)   A p rebuilt from three rows of the stored direction, r -= alpha Ap, x update (every second
-//                           iteration, two steps at once; every iteration for the MSG rule), partial sums / maxes of
+//   k_update_st (phase B)   A p rebuilt from three rows of the stored direction, r -= alpha Ap, x update (every fourth
+//                           iteration, four steps at once; every iteration for the MSG rule), partial sums / maxes of
 //                           r.r, |r|, |dx|, |x-u|.  Replaces matrix_free_system.cpp:422-455 / msg_solver.cpp:105-139.
 //   k_update                flat variant: state initialisation, resume step of the mixed-precision path, CSR handles.
 //   k_check, k_flush_x, k_make_record, k_scatter_ghosts, k_pack/k_unpack, k_sub, k_resid2, ...: small helpers.
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
 // starts on the rows that launch touched last -- keeps three rows of p in registers and evaluates the 5-point formula
 // again: same operands, same operation order, hence the same bits as the values the stencil launch reduced into
 // (Ap, p).  A p never touches HBM.  XM selects what happens to x in this launch:
-//   0  nothing (odd iterations of the two-step scheme below);
+//   0  nothing (the iterations between two folded updates, see M below);
 //   1  x += alpha p plus the norms |dx|, |x - u| (MSG rule every iteration; REL_2NORM with per-iteration diagnostics);
 //   M = 2 or 4  folded update on iterations k = 0 mod M: x = (..(x + alpha_{k-M+1} p_{k-M+1}) + ..) + alpha_k p_k.  The M - 1 earlier
 //      directions are still intact in the other buffers of the direction ring, their step lengths are in the state

@@ -149,3 +149,12 @@ def test_config4_16384_as_4_row_slabs_matches_one_gpu():
 def test_config5_32768_as_8_parts_matches_one_gpu():
     """BASELINE config 5: N = 32768 (805 M unknowns) over 8 parts (4 x 2), 12 iterations; 2 x 45 GB of vectors on the card."""
     _big(32768, 8, 1, 12)
+
+
+@pytest.mark.parametrize("world,n,decomp", [(2, 5792, 0), (4, 8192, 0), (8, 11586, 0), (4, 8192, 1), (8, 11586, 1)])
+def test_bench_weak_scaling_geometries_match_one_gpu(world, n, decomp):
+    """The grids bench.py --gpus N runs (weak scaling: config-2-sized parts, N = 4096 sqrt(world) rounded to even; 11586 has an
+    odd N/2), as LOCAL teams on one GPU, a fixed 24 iterations."""
+    from iterative_solvers_amd.distributed import weak_scaling_n
+    assert weak_scaling_n(4096, world) == n
+    _big(n, world, decomp, 24)
