@@ -112,6 +112,7 @@ struct mi355cg_ctx {
     // hipGraph cache for launch-bound (small) grids: one instantiated graph per distinct chunk shape of a solve
     struct ChunkGraph { int m, cur; std::vector<char> flags; hipGraphExec_t exec; };
     std::vector<ChunkGraph> graphs;
+    mi355cg_params graph_prm{};          // parameters the cached graphs were captured with
     int use_graph = -1;                 // env MI355CG_GRAPH: -1 auto (small grids), 0 off, 1 on
 
     hipEvent_t ev_loop[2] = {nullptr, nullptr};   // brackets the iterations of the last solve (mi355cg_results::loop_seconds)
@@ -1086,7 +1087,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     // A caller that watches the solve (callback or stop flag) gets the first iteration on its own: the it == 1 callback
     // is delivered, and a stop requested from it is honoured, before any further work is queued.
     bool first_chunk = cb != nullptr || stop_flag != nullptr;
-    clear_graphs(c);                                             // kernel arguments embed this solve's parameters
+    if (std::memcmp(&c->graph_prm, prm, sizeof *prm) != 0) { clear_graphs(c); c->graph_prm = *prm; }     // kernel arguments embed the solve's parameters: graphs live as long as those do
     const bool graph_ok = !c->profiling && !diag &&
                           (c->use_graph == 1 || (c->use_graph < 0 && c->g.own_len < (4LL << 20) && prm->max_iterations >= 4 * sync_every));
     while (!c->summary_h->done) {
