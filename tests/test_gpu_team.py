@@ -158,3 +158,23 @@ def test_bench_weak_scaling_geometries_match_one_gpu(world, n, decomp):
     from iterative_solvers_amd.distributed import weak_scaling_n
     assert weak_scaling_n(4096, world) == n
     _big(n, world, decomp, 24)
+
+
+def test_team_lifecycle_cycles_and_interleaved_handles():
+    """Teams, single contexts and solves interleaved and torn down repeatedly: no stale state, no leaked events / streams."""
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    ref = None
+    for cycle in range(12):
+        t = Team.local(130, 2 + cycle % 5, cycle % 2)
+        s = isa.MatrixFreeSystem(130, 130, 1.0, 2.0, 1.0, 2.0)
+        p = _params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 5)
+        r1 = s._handle.solve(p)
+        rt = t.solve(p)
+        rt2 = t.solve(p)                                           # a team is reusable; same answer again
+        if ref is None:
+            ref = (r1.iterations, r1.r_norm2, s._handle.solution())
+        for r in (r1, rt, rt2):
+            assert (r.iterations, r.r_norm2) == ref[:2]
+        assert np.array_equal(t.vector(0), ref[2]) and np.array_equal(s._handle.solution(), ref[2])
+        t.close(); s._handle.close()
