@@ -171,6 +171,17 @@ def bench_team(args, rule):
 
 
 def main():
+    # ONE JSON line on stdout: libraries chat there too (RCCL prints a version banner when its first communicator comes up),
+    # so everything else this process writes to fd 1 goes to stderr until the line is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -200,7 +211,7 @@ def main():
     if world > 1 or args.gpus > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1":
         out = bench_team(args, rule)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         return
 
     n = args.n
@@ -273,7 +284,7 @@ def main():
     }
     if args.cpu_iters > 0 and not f32:
         out["cpu_baseline"] = cpu_baseline(n, args.cpu_iters)
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <unistd.h>
 
 static void jvec(const char* key, const std::vector<double>& v, bool last = false) {
     std::printf("\"%s\": [", key);
@@ -84,6 +85,33 @@ int main(int argc, char** argv) {
         const bool same_dist = q.iterations == r.iterations && q.converged == r.converged && q.stop_reason == r.stop_reason &&
                                q.solution == r.solution && q.residual == r.residual && q.residual_norm == r.residual_norm && q.error_norm == r.error_norm;
         std::printf("\"dist_same_as_one_gpu\": %d, \"dist_iterations\": %d, \"dist_callbacks\": %d,\n", same_dist ? 1 : 0, q.iterations, (int)cb_its.size());
+    }
+    {   // the team surface of the C ABI from C++ (what an MPI-launched host would do per rank; here world = 1):
+        // ncclGetUniqueId -> ncclCommInitRank inside the library, then the same solve call as on a single handle
+        unsigned char id[128];
+        mi355cg_team team = nullptr;
+        mi355cg_params p;
+        mi355cg_default_params(&p, MI355CG_RULE_REL_2NORM);
+        p.eps_rel = 1e-8; p.max_iterations = 1000000;
+        mi355cg_results tr{}, sr{};
+        // RCCL prints a version banner on stdout when its first communicator comes up: keep this program's JSON clean
+        std::fflush(stdout);
+        const int saved_stdout = dup(1);
+        dup2(2, 1);
+        mi355cg_compat::check(mi355cg_team_unique_id(id));
+        mi355cg_compat::check(mi355cg_team_create_rccl(N, N, 1.0, 2.0, 1.0, 2.0, 1, 0, 0, id, MI355CG_DECOMP_ROWS, &team));
+        std::fflush(stdout);
+        dup2(saved_stdout, 1);
+        close(saved_stdout);
+        mi355cg_compat::check(mi355cg_team_solve(team, &p, nullptr, nullptr, nullptr, &tr));
+        MatrixFreeSystem one(N, N, 1.0, 2.0, 1.0, 2.0);
+        mi355cg_compat::check(mi355cg_solve(one.context()->h, &p, nullptr, nullptr, nullptr, &sr));
+        std::vector<double> xt(one.size(), -1.0), xs(one.size());
+        mi355cg_compat::check(mi355cg_team_get_vector(team, 0, xt.data()));
+        mi355cg_compat::check(mi355cg_get_solution(one.context()->h, xs.data()));
+        std::printf("\"rccl_team_iterations\": %d, \"rccl_team_same_as_handle\": %d,\n", tr.iterations,
+                    (tr.iterations == sr.iterations && tr.r_norm2 == sr.r_norm2 && xt == xs) ? 1 : 0);
+        mi355cg_team_destroy(team);
     }
     {   // matrix-free pair
         MatrixFreeSystem sys(N, N, 1.0, 2.0, 1.0, 2.0);

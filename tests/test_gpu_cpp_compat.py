@@ -70,6 +70,7 @@ def test_cpp_dropin_matches_oracle(N):
     # matrix-free pair
     mf = og.mf_solve(eps=1e-8, max_iterations=10 ** 6)
     assert (j["mf_iterations"], j["mf_completed_ok"]) == (mf.iterations, 1)
+    assert (j["rccl_team_iterations"], j["rccl_team_same_as_handle"]) == (mf.iterations, 1)      # team surface of the C ABI, called from C++
     assert np.array_equal(np.array(j["mf_apply_ones"]), og.apply(np.ones(og.size)))
     assert np.abs(np.array(j["mf_x"]) - mf.x).max() <= 1e-9 * np.abs(mf.x).max()
     # ---- file formats, restated here from solver/dirichlet_solver.cpp:255-457 and
