@@ -213,6 +213,11 @@ typedef struct mi355cg_halo_msg {
 /* pure host arithmetic (no GPU needed): the box of `rank`, and its halo messages per iteration */
 int  mi355cg_decompose(int n, int world, int decomp, int rank, int *y_lo, int *y_hi, int *x_lo, int *x_hi);
 int  mi355cg_halo_plan(int n, int world, int decomp, int rank, int max_msgs, int *n_msgs, mi355cg_halo_msg *msgs);
+/* for tests (host arithmetic only): the work items of a part's launches.  which: 0 whole part, 1 interior, 2 edge.
+ * panels: 8 ints per panel {y0, y1, first strip, strips, item rows, chunks, first item, ghost-column flags};
+ * cls: [0] = number of XCD classes, [1..9] = their item boundaries                                                    */
+int  mi355cg_debug_plan(int n, int world, int decomp, int rank, int which, int *n_panels, int *panels,
+                        int *grid, int *n_items, int *cls);
 /* LOCAL transport: this process drives all `world` parts; part r runs on devices[r % ndevices] (NULL: device 0).
  * Parts on different GPUs need peer access (xGMI).                                                                   */
 int  mi355cg_team_create_local(int n, int m, double a, double b, double c, double d, int world,

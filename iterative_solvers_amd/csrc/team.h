@@ -605,6 +605,33 @@ int mi355cg_halo_plan(int n, int world, int decomp, int rank, int max_msgs, int*
     return MI355CG_OK;
 }
 
+// Pure host arithmetic, for tests: the launch plan (work items) a part of the given decomposition would get.
+// which: 0 whole part, 1 interior items, 2 edge items.  panels: up to 8 rows of {y0, y1, s0, ns, ty, nchunks, item0, gc};
+// cls: ncls followed by the class boundaries (ncls + 1 values) when ncls > 1.  Returns the number of panels in *np.
+int mi355cg_debug_plan(int n, int world, int decomp, int rank, int which, int* np, int* panels, int* grid, int* nitems, int* cls) {
+    GridParams gp;
+    if (!grid_params_init(&gp, n, n, 0, 1, 0, 1)) return fail(MI355CG_ERR_INVALID, "grid %d rejected", n);
+    if (world < 1 || rank < 0 || rank >= world || !np || !panels) return fail(MI355CG_ERR_INVALID, "bad argument");
+    std::vector<Box> bx;
+    if (int rc = decompose(gp, world, decomp, bx)) return rc;
+    mi355cg_ctx c{};                                   // geometry and plans only: no device is touched
+    c.gp = gp; c.dtype = MI355CG_F64; c.is_slab = world > 1;
+    c.s_lo = bx[rank].s_lo; c.s_hi = bx[rank].s_hi;
+    build_geom(&c, 2, bx[rank].y_lo, bx[rank].y_hi);
+    build_plans(&c);
+    const Plan& pl = which == 1 ? c.interior : which == 2 ? c.edge : c.whole;
+    *np = pl.wl.np;
+    for (int k = 0; k < pl.wl.np; ++k) {
+        const Panel& P = pl.wl.p[k];
+        const int row[8] = {P.y0, P.y1, P.s0, P.ns, P.ty, P.nchunks, P.item0, P.gc};
+        std::memcpy(panels + 8 * k, row, sizeof row);
+    }
+    if (grid) *grid = pl.grid;
+    if (nitems) *nitems = pl.wl.nitems;
+    if (cls) { cls[0] = pl.wl.ncls; for (int k = 0; k <= kXcds; ++k) cls[1 + k] = pl.wl.ncls == kXcds ? pl.wl.cls0[k] : 0; }
+    return MI355CG_OK;
+}
+
 static int team_create_common(int n, int m, double a, double b, double c_, double d, int world, int decomp, mi355cg_team_s** out_t) {
     if (!out_t) return fail(MI355CG_ERR_INVALID, "out is null");
     *out_t = nullptr;

@@ -154,3 +154,64 @@ def test_halo_plan_delivers_what_the_operator_needs_over_gloo(world, n, decomp):
         allidx = np.sort(np.concatenate(seen))
         U = (n // 2 - 1) * (3 * n // 2 - 1)
         assert np.array_equal(allidx, np.arange(U))                          # every unknown on exactly one rank
+
+
+def _plan(n, world, decomp, rank, which):
+    import ctypes as C
+    from iterative_solvers_amd import _capi
+    lib = _capi.load()
+    np_, grid, nitems = C.c_int(), C.c_int(), C.c_int()
+    panels = (C.c_int * 64)()
+    cls = (C.c_int * 10)()
+    _capi.check(lib.mi355cg_debug_plan(n, world, decomp, rank, which, C.byref(np_), panels, C.byref(grid), C.byref(nitems), cls))
+    P = [tuple(panels[8 * k:8 * k + 8]) for k in range(np_.value)]
+    return P, grid.value, nitems.value, list(cls)
+
+
+def _cover(panels):
+    """{(y, strip): count} of a panel list, and per-item consistency of the chunking."""
+    cov = {}
+    items = 0
+    for (y0, y1, s0, ns, ty, nch, item0, gc) in panels:
+        assert item0 == items and ty >= 1 and nch == -(-(y1 - y0 + 1) // ty)
+        items += ns * nch
+        for y in range(y0, y1 + 1):
+            for s in range(s0, s0 + ns):
+                cov[(y, s)] = cov.get((y, s), 0) + 1
+    return cov, items
+
+
+@pytest.mark.parametrize("n,world,decomp", [(64, 1, 0), (258, 1, 0), (258, 4, 1), (514, 8, 1), (130, 3, 0), (1026, 4, 1), (4096, 1, 0), (4096, 4, 1), (66, 16, 0)])
+def test_launch_plans_tile_every_part_exactly_once(n, world, decomp):
+    """Work items of the whole-part launch cover each (row, 128-column strip) of the part once; interior + edge launches are a
+    partition of the same set; XCD class boundaries are monotone and end at the item count."""
+    from iterative_solvers_amd.distributed import decompose
+    half = n // 2
+    ns_all = (n - 1) // 128 + 1
+    s0b = (half + 1) // 128
+    seen_rows = set()
+    for rank, (y_lo, y_hi, x_lo, x_hi) in enumerate(decompose(n, world, decomp)):
+        want = set()
+        s_lo, s_hi = x_lo // 128, (ns_all if x_hi >= n else x_hi // 128)
+        for y in range(y_lo, y_hi + 1):
+            for s in range(max(s_lo, s0b) if y <= half else s_lo, s_hi):
+                want.add((y, s))
+        whole, grid, nitems, cls = _plan(n, world, decomp, rank, 0)
+        cov, items = _cover(whole)
+        assert items == nitems and set(cov) == want and set(cov.values()) <= {1}
+        assert 1 <= grid <= 512
+        if cls[0] == 8:
+            assert cls[1] == 0 and cls[9] == nitems and all(cls[k] <= cls[k + 1] for k in range(1, 9)) and grid % 8 == 0
+        inner, _, ni, _ = _plan(n, world, decomp, rank, 1)
+        edge, _, ne, _ = _plan(n, world, decomp, rank, 2)
+        ci, _ = _cover(inner)
+        ce, _ = _cover(edge)
+        assert set(ci) | set(ce) == want and not (set(ci) & set(ce))
+        assert set(ci.values()) <= {1} and set(ce.values()) <= {1}
+        # everything that touches a ghost row or a ghost column is an edge item
+        for (y, s) in ci:
+            assert y_lo < y < y_hi
+        for (y0, y1, s0, ns, ty, nch, item0, gc) in edge:
+            assert gc in (0, 1, 2, 3)
+        seen_rows |= {y for (y, s) in want}
+    assert seen_rows == set(range(1, n))
