@@ -26,6 +26,7 @@ constexpr int kWave = 64;
 constexpr int kWaves = kBlock / kWave;
 constexpr int kHist = 512;            // per-iteration norm history ring (>= sync_every)
 constexpr int kMaxPanels = 8;
+constexpr int kRing = 8;              // direction buffers of a context (ring; M = xsteps <= kRing of them are in use); also the alpha history depth
 
 // ---- per-wave timing probe (diagnostic build only: -DMI355CG_WAVE_TIMING, tools/wave_timing.py) -------------------
 // Every wave of the two iteration kernels records wall_clock64() (100 MHz) at entry, after the prologue and at exit.
@@ -102,7 +103,7 @@ struct CgState {
     double rnorm2;      // ||r||_2
     double rmax, dmax, emax, d2, e2;
     int it, done, reason, converged, first, pad_;
-    double alpha_hist[4];   // step length of iteration k at [k & 3]: the folded x update (XM >= 2) applies up to three earlier steps at once
+    double alpha_hist[kRing];   // step length of iteration k at [k % kRing]: the folded x update (XM >= 2) applies up to kRing - 1 earlier steps at once
 };
 struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2, tr2; };   // tr2: ||b - A x||_2^2 (REL_2NORM diagnostics mode, written by k_resid2_hist)
 
@@ -819,8 +820,8 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
                 if (a.init == 2) {
                     if (s.done) o->rr = s.rr_prev;
                     o->done = 0; o->reason = 0; o->converged = 0; o->alpha = 0.0; o->r0norm = a.r0norm_resume;
-                    for (int i = 0; i < 4; ++i) o->alpha_hist[i] = 0.0;
-                } else { o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; o->alpha_hist[(s.it + 1) & 3] = alpha_d; }
+                    for (int i = 0; i < kRing; ++i) o->alpha_hist[i] = 0.0;
+                } else { o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; o->alpha_hist[(s.it + 1) & (kRing - 1)] = alpha_d; }
             }
         }
     }
@@ -843,7 +844,7 @@ struct UpdateStArgs {
     Geom g;
     WorkList wl;
     const T* p;          // current direction, ghost rows / columns valid
-    const T* pprev[3];   // XM >= 2: the directions of the 1, 2, 3 iterations before (the other buffers of the ring)
+    const T* pprev[kRing - 1];   // XM >= 2: the directions of the 1, 2, ... iterations before (the other buffers of the ring)
     T* r; T* x; const T* u;
     const double* partA; int nA, strideA, esA;
     double* partB; int strideB, slotB;
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     MI355CG_WT_MID
     T aprev[NP > 0 ? NP : 1] = {(T)0};     // XM >= 2: step lengths of iterations k-1, k-2, k-3 (k = s.it + 1; 0 after init / resume)
 #pragma unroll
-    for (int i = 0; i < NP; ++i) aprev[i] = (T)scalar_load(&a.s_in->alpha_hist[(s.it - i) & 3]);
+    for (int i = 0; i < NP; ++i) aprev[i] = (T)scalar_load(&a.s_in->alpha_hist[(s.it - i) & (kRing - 1)]);
     const T cA = (T)g.A, cxk = (T)g.xk, cyk = (T)g.yk;
     dd s_rr = dd_zero(), s_d2 = dd_zero(), s_e2 = dd_zero();
     double s_rmax = 0, s_dmax = 0, s_emax = 0;
@@ -1042,7 +1043,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
         if (blockIdx.x == 0) {
             copy_state(a.s_out, a.s_in);
             CgState* o = a.s_out;
-            o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; o->alpha_hist[(s.it + 1) & 3] = alpha_d;
+            o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; o->alpha_hist[(s.it + 1) & (kRing - 1)] = alpha_d;
         }
     }
     arrive_and_record(1, a.partB, a.strideB, a.rec, lds);
@@ -1066,8 +1067,8 @@ __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
 }
 
 // The x updates still pending when the folded loop ends on a count that is not a multiple of M (up to three): over the
-// part's own cells, x = ((x + a[0] p[0]) + a[1] p[1]) + a[2] p[2], oldest step first.
-template <typename T> struct FlushArgs { const T* p[3]; T a[3]; int n; };
+// part's own cells, x = ((x + a[0] p[0]) + a[1] p[1]) + ..., oldest step first.
+template <typename T> struct FlushArgs { const T* p[kRing - 1]; T a[kRing - 1]; int n; };
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_flush_x(const Geom g, const WorkList wl, T* x, const FlushArgs<T> f) {
     typedef typename VecOf<T, VEC>::type vec_t;
@@ -1081,7 +1082,7 @@ __global__ __launch_bounds__(kBlock) void k_flush_x(const Geom g, const WorkList
             const long long off = row_off(g, y) - g.base0 + x0;
             vec_t xn = *reinterpret_cast<const vec_t*>(x + off);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) if (k < f.n) {
+            for (int k = 0; k < kRing - 1; ++k) if (k < f.n) {
                 const vec_t pv = *reinterpret_cast<const vec_t*>(f.p[k] + off);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) xn[j] = xn[j] + f.a[k] * pv[j];          // x = x + alpha*z

@@ -44,7 +44,6 @@ int env_int(const char* name, int dflt) {
 inline long long round_up(long long v, long long m) { return (v + m - 1) / m * m; }
 
 constexpr int kRecHeader = kRecWords;     // doubles reserved for the sums (hi/lo pairs) and maxes at the head of a part's record
-constexpr int kRing = 4;           // direction buffers of a context (ring; M = xsteps of them are in use)
 constexpr int kStripCols = 128;    // fp64 strip = 64 lanes x double2: the unit of the x-cuts of a 2-D decomposition
 
 struct EventPool {
@@ -81,10 +80,10 @@ struct mi355cg_ctx {
     int strideA = 0, strideB = 0;
 
     // device vectors in storage layout (fp64 set always; fp32 set for F32_MIXED)
-    double *x = nullptr, *r = nullptr, *p[kRing] = {nullptr, nullptr, nullptr, nullptr}, *ap = nullptr, *b = nullptr, *u = nullptr;
-    int xsteps = 4;                     // M: the direction ring has M buffers, x is touched every M-th iteration (env MI355CG_XSTEPS: 2 | 4)
+    double *x = nullptr, *r = nullptr, *p[kRing] = {}, *ap = nullptr, *b = nullptr, *u = nullptr;
+    int xsteps = 4;                     // M: the direction ring has M buffers, x is touched every M-th iteration (env MI355CG_XSTEPS: 2 | 4 | 8)
     double* scratch[2] = {nullptr, nullptr};      // mi355cg_apply / true residual work space, allocated on first use: never a solver vector
-    float *xf = nullptr, *rf = nullptr, *pf[kRing] = {nullptr, nullptr, nullptr, nullptr}, *apf = nullptr;
+    float *xf = nullptr, *rf = nullptr, *pf[kRing] = {}, *apf = nullptr;
     double* packed = nullptr;           // device scratch, pk_len doubles
     double *partA = nullptr, *partB = nullptr, *partR = nullptr;
     double *sumsA = nullptr, *sumsB = nullptr;   // slab mode: this rank's record = reduced partials [+ its two boundary rows] (feeds the all-gather)
@@ -356,7 +355,7 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
     UpdateStArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
     a.p = p[c->cur]; a.r = r; a.x = x; a.u = u;
-    for (int i = 0; i < 3; ++i) a.pprev[i] = p[(c->cur + 2 * c->xsteps - 1 - i) % c->xsteps];      // directions of iterations k-1, k-2, k-3
+    for (int i = 0; i < kRing - 1; ++i) a.pprev[i] = p[(c->cur + 2 * kRing * c->xsteps - 1 - i) % c->xsteps];      // directions of iterations k-1, k-2, ...
     a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
     a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slot;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
@@ -366,7 +365,7 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
 #define MI355CG_UST(XM, HASU) do { if (d3) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 3, true>), grid, block, 0, w.stream, a); \
                                    else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, true>), grid, block, 0, w.stream, a); } while (0)
     if (cfg.x2) {                    // iterations k = 0 mod M carry all M x steps (c->cur = k % M)
-        if (c->cur != 0) MI355CG_UST(0, false); else if (c->xsteps == 4) MI355CG_UST(4, false); else MI355CG_UST(2, false);
+        if (c->cur != 0) MI355CG_UST(0, false); else if (c->xsteps == 8) MI355CG_UST(8, false); else if (c->xsteps == 4) MI355CG_UST(4, false); else MI355CG_UST(2, false);
     }
     else if constexpr (VEC == 2) { if (cfg.has_u) MI355CG_UST(1, true); else MI355CG_UST(1, false); }
 #undef MI355CG_UST
@@ -394,7 +393,7 @@ void launch_flush_x(const mi355cg_ctx* c, const Plan& plan, T* x, T* const p[kRi
     if (plan.wl.nitems == 0 || pending == 0) return;
     FlushArgs<T> f{};
     f.n = pending;
-    for (int j = 0; j < pending; ++j) { const int k = fin.it - pending + 1 + j; f.p[j] = p[k % c->xsteps]; f.a[j] = (T)fin.alpha_hist[k & 3]; }
+    for (int j = 0; j < pending; ++j) { const int k = fin.it - pending + 1 + j; f.p[j] = p[k % c->xsteps]; f.a[j] = (T)fin.alpha_hist[k & (kRing - 1)]; }
     hipLaunchKernelGGL((k_flush_x<T, VEC>), dim3(std::max(1, std::min(1024, (plan.wl.nitems + kWaves - 1) / kWaves))), dim3(kBlock), 0, stream,
                        kernel_geom<T, VEC>(c), plan.wl, x, f);
 }
@@ -785,11 +784,13 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     auto cleanup = [&]() { mi355cg_destroy(c); return rc; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "hipStreamCreate failed"); return cleanup(); }
     const long long L = c->storage_len;
-    c->xsteps = env_int("MI355CG_XSTEPS", 4) == 2 ? 2 : 4;
-    double** vecs[] = {&c->x, &c->r, &c->p[0], &c->p[1], &c->ap, &c->b, &c->u, &c->p[2], &c->p[3]};
+    // x is folded every M-th iteration: 4 by default.  8 saves another 0.125 words per iteration and measured +0.2-0.7 % for
+    // four more vectors (fp64 only: the fp32 8-step launch needs 262 VGPRs and would halve the resident waves)
+    { const int m = env_int("MI355CG_XSTEPS", 4); c->xsteps = m == 2 ? 2 : ((m == 8 && dtype == MI355CG_F64) ? 8 : 4); }
+    double** vecs[] = {&c->x, &c->r, &c->p[0], &c->p[1], &c->ap, &c->b, &c->u, &c->p[2], &c->p[3], &c->p[4], &c->p[5], &c->p[6], &c->p[7]};
     for (int k = 0; k < 7 + (c->xsteps - 2); ++k) if ((rc = alloc_vec(vecs[k], L))) return cleanup();
     if (dtype == MI355CG_F32_MIXED) {
-        float** fv[] = {&c->xf, &c->rf, &c->pf[0], &c->pf[1], &c->apf, &c->pf[2], &c->pf[3]};
+        float** fv[] = {&c->xf, &c->rf, &c->pf[0], &c->pf[1], &c->apf, &c->pf[2], &c->pf[3], &c->pf[4], &c->pf[5], &c->pf[6], &c->pf[7]};
         const int nfv = 5 + (c->xsteps - 2);
         for (int k = 0; k < nfv; ++k) {
             float** v = fv[k];
@@ -922,7 +923,8 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->p[2], c->p[3], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf, c->pf[0], c->pf[1], c->pf[2], c->pf[3], c->apf,
+    void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->p[2], c->p[3], c->p[4], c->p[5], c->p[6], c->p[7], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf,
+                   c->pf[0], c->pf[1], c->pf[2], c->pf[3], c->pf[4], c->pf[5], c->pf[6], c->pf[7], c->apf,
                    c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist, c->ticket};
     for (void* p : dev) if (p) hipFree(p);
     if (c->csr_row_map) hipFree(c->csr_row_map);

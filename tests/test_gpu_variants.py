@@ -17,6 +17,7 @@ VARIANTS = [
     {"MI355CG_DEPTH": "3", "MI355CG_ITEM_ROWS": "1"},
     {"MI355CG_BLOCKS": "37"},
     {"MI355CG_WAVES": "256", "MI355CG_ITEM_ROWS": "5"},
+    {"MI355CG_XSTEPS": "8"},                                # x folded every 8th iteration (12-word launch, 247 VGPRs)
     {"MI355CG_XSTEPS": "2"},                                # x folded every 2nd iteration instead of every 4th (round 1's scheme)
     {"MI355CG_XCD_CLASSES": "0"},                           # items dealt to all workgroups alike (no per-XCD ranges)
     {"MI355CG_BLOCKS": "100", "MI355CG_ITEM_ROWS": "9"},    # grid not a multiple of 8 XCD classes -> rounded down to 96
