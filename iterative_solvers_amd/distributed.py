@@ -253,7 +253,7 @@ class DistResults:
 class DistributedCG:
     """CG over row slabs.  `engine` implements the SlabEngine protocol."""
 
-    def __init__(self, engine, group=None, halo: str = "gather", overlap: bool = True):
+    def __init__(self, engine, group=None, halo: str = "p2p", overlap: bool = True):
         assert halo in ("gather", "p2p")
         self.eng = engine
         self.comm = _Comm(group)
@@ -278,7 +278,22 @@ class DistributedCG:
             eng.reduce(which, with_rows=False)
             comm.all_gather(self.gA if which == 0 else self.gB, eng.record(which)[:eng.rec_header])
 
-    def solve(self, params: _capi.Params, callback=None) -> DistResults:
+    def _stop_anywhere(self, stop) -> bool:
+        """A stop request on any rank stops every rank at the same poll (one tiny all-gather per poll)."""
+        if stop is None:
+            return False
+        mine = torch.tensor([1.0 if stop() else 0.0], dtype=torch.float64)
+        if self.comm.world == 1:
+            return bool(mine.item())
+        if not self.comm.stage:
+            mine = mine.to(self.gA.device)
+        out = torch.zeros(self.comm.world, dtype=torch.float64, device=mine.device)
+        self.comm.all_gather(out, mine)
+        return bool(out.max().item() > 0)
+
+    def solve(self, params: _capi.Params, callback=None, stop=None) -> DistResults:
+        """stop: optional callable; when it returns True on ANY rank the loop ends at the next poll on ALL ranks with
+        stop reason INTERRUPTED (msg_solver.cpp:82-87; the reference polls every iteration, this harness every chunk)."""
         eng, comm, W = self.eng, self.comm, self.W
         p2p = self.halo == "p2p"
         msg = params.rule == _capi.RULE_MSG_MAXNORM
@@ -296,8 +311,15 @@ class DistributedCG:
         it_done = 0
         WA = self.WA
         assert not eng.update_reads_ghosts                  # the stencil phase keeps the direction's ghost rows itself
+        interrupted = False
+        first = callback is not None or stop is not None
         while not done:
+            if self._stop_anywhere(stop):
+                interrupted = True
+                break
             m = min(sync_every, max(1, params.max_iterations - it_done))
+            if first:
+                m, first = 1, False
             if msg and every > 0:
                 m = min(m, every - it_done % every)
             for _ in range(m):
@@ -326,6 +348,10 @@ class DistributedCG:
         eng.finish()                                        # flush the x update still pending after an odd iteration count
         if msg and callback:
             callback(res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm)
+        if interrupted:
+            return DistResults(res.iterations, False, _capi.STOP_INTERRUPTED, res.final_residual_norm,
+                               res.final_precision, res.final_error_norm, res.r_norm2, res.initial_r_norm2,
+                               time.perf_counter() - t0)
         return DistResults(res.iterations, bool(res.converged), res.stop_reason, res.final_residual_norm,
                            res.final_precision, res.final_error_norm, res.r_norm2, res.initial_r_norm2,
                            time.perf_counter() - t0)

@@ -98,3 +98,37 @@ def test_slab_partition_covers_grid_and_balances():
             cnt = [sum((half - 1) if y <= half else (n - 1) for y in range(lo, hi + 1)) for lo, hi in rows]
             assert max(cnt) / min(cnt) < 1.01
     assert [weak_scaling_n(4096, p) for p in (1, 2, 4, 8)] == [4096, 5792, 8192, 11586]
+
+
+def _stop_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from iterative_solvers_amd import _capi
+        from iterative_solvers_amd.distributed import DistributedCG, slab_rows
+        from iterative_solvers_amd.solver import default_params
+        from slab_oracle_engine import OracleSlabEngine
+        n = 24
+        y_lo, y_hi = slab_rows(n, world, rank)
+        cg = DistributedCG(OracleSlabEngine(n, y_lo, y_hi))
+        p = default_params(_capi.RULE_MSG_MAXNORM)
+        p.eps_precision = p.eps_residual = 1e-30
+        p.eps_exact_error = -1.0
+        seen = []
+        # only rank 1 asks for the stop, from its it == 1 callback: every rank must leave the loop at iteration 1
+        res = cg.solve(p, callback=lambda it, *a: seen.append(it), stop=lambda: rank == 1 and 1 in seen)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), it=res.iterations, reason=res.stop_reason, conv=res.converged)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stop_request_on_one_rank_stops_all_ranks_at_the_same_iteration():
+    world = 3
+    port = 29000 + (os.getpid() * 3 + 977) % 2000
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_stop_worker, args=(world, port, d), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+    assert [int(p["it"]) for p in parts] == [1, 1, 1]
+    assert all(int(p["reason"]) == 4 and not bool(p["conv"]) for p in parts)        # INTERRUPTED (msg_solver.cpp:82-87)
