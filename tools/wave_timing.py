@@ -78,3 +78,40 @@ for name, a, b in (("stencil launch vs update launch (same solve)", first[0][:nb
         a2[par == x] -= np.nanmean(a[par == x]); b2[par == x] -= np.nanmean(b[par == x])
     print(f"per-workgroup duration correlation, {name}: raw {np.corrcoef(a[m], b[m])[0, 1]:.3f}, XCD means removed {np.corrcoef(a2[m], b2[m])[0, 1]:.3f} "
           f"(std {np.nanstd(a2):.2f} / {np.nanstd(b2):.2f} us)")
+
+
+# Where on the grid are the slow items?  (one item per wave: N <= 4096 with the default plan)
+def item_map(dd, k, reverse):
+    import ctypes as C
+    lib = _capi.load()
+    np_, grid, nitems = C.c_int(), C.c_int(), C.c_int()
+    panels = (C.c_int * 64)()
+    cls = (C.c_int * 10)()
+    _capi.check(lib.mi355cg_debug_plan(N, 1, 0, 0, 0, C.byref(np_), panels, C.byref(grid), C.byref(nitems), cls))
+    P = [tuple(panels[8 * i:8 * i + 8]) for i in range(np_.value)]
+    if cls[0] != 8 or nitems.value > grid.value * 4:
+        return
+    w = dd[k]
+    dur = np.where(w[:, 5] > 0, (w[:, 5] - w[:, 4]) / 100.0, np.nan)
+    print(f"--- main loop (us) of launch kind {k} by grid position (rows: chunk rows bottom -> top; columns: 128-column strips), N = {N}")
+    maps = {i: np.full((p[5], p[3]), np.nan) for i, p in enumerate(P)}
+    for wave in range(min(len(dur), grid.value * 4)):
+        b, wl = divmod(wave, 4)
+        c = b % 8
+        begin, end = cls[1 + c], cls[2 + c]
+        idx = begin + (b // 8) * 4 + wl
+        if idx >= end or np.isnan(dur[wave]):
+            continue
+        item = end - 1 - (idx - begin) if reverse else idx
+        pi = max(i for i, p in enumerate(P) if item >= p[6])
+        local = item - P[pi][6]
+        maps[pi][local // P[pi][3], local % P[pi][3]] = dur[wave]
+    for i, p in enumerate(P):
+        print(f"panel {i}: rows {p[0]}..{p[1]}, strips {p[2]}..{p[2] + p[3] - 1}, {p[4]} rows per item; column means:",
+              " ".join(f"{v:4.0f}" for v in np.nanmean(maps[i], axis=0)))
+        for r in range(maps[i].shape[0]):
+            print(f"  chunk {r:3d} (mean {np.nanmean(maps[i][r]):5.1f}):", " ".join(f"{v:4.0f}" for v in maps[i][r]))
+
+
+item_map(d2, 0, False)
+item_map(d2, 1, True)
