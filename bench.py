@@ -137,6 +137,26 @@ def bench_team(args, rule):
         phases = team.phase_times()
         phases["driver_and_wait_ms"] = max(0.0, phases["wall_ms"] - phases["kernels_ms"])
         phases["note"] = "rank 0, per iteration: device time of its kernels; device time of the collectives + halo messages on the comm stream (they overlap the kernels); wall"
+    # Cross-check of the distributed loop (untimed): V iterations on the team against the SAME global problem solved by ONE context
+    # on rank 0's GPU.  The team's reductions are summed part by part in a fixed order, so the residual norm has to agree to
+    # rounding of the last bit or two; a halo row that arrived late or in the wrong place shows up in the leading digits.
+    verify = None
+    if (world > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1") and args.verify > 0:
+        if U <= args.verify_max_unknowns:
+            rv = run(args.verify)
+            torch.cuda.synchronize()
+            if rank == 0:
+                one = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=local_rank)
+                p = isa.default_params(rule)
+                p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = args.verify, 1, 0, 0, 500
+                r1 = one._handle.solve(p)
+                one._handle.close()
+                rel = abs(rv.r_norm2 - r1.r_norm2) / max(abs(r1.r_norm2), 1e-300)
+                verify = {"iterations": args.verify, "team_r_norm2": rv.r_norm2, "single_gpu_r_norm2": r1.r_norm2,
+                          "rel_diff": rel, "ok": bool(rel <= 1e-12 and rv.iterations == r1.iterations)}
+            dist.barrier()
+        else:
+            verify = {"skipped": f"{U} unknowns > --verify-max-unknowns {args.verify_max_unknowns}"}
     bytes_it = 8.0 * sum(WORDS[args.rule].values())
     units = 1.0 if strong else U / U1
     moved = bytes_it * U * its / 1e9 / world
@@ -156,6 +176,7 @@ def bench_team(args, rule):
         "hbm_gbps_is": f"bytes really moved, summed over GPUs: {bytes_it:.0f} B per unknown per iteration",
         "algorithmic_equivalent_gbps_88B": round(SURVEY_BYTES_PER_UNKNOWN * U * its / 1e9, 1),
         "phases_ms": phases,
+        "verify_against_one_gpu": verify,
         # whole-iteration roofline per GPU (kernels + collectives + driver); the per-kernel figures are in the 1-GPU bench line
         "roofline": {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(moved / HBM_PEAK_GBPS, 4),
                      "traffic": None, "scope": "bytes one GPU has to move per iteration / wall time per iteration, collectives included"},
@@ -194,7 +215,21 @@ def main():
     ap.add_argument("--decomp", choices=["rows", "2d"], default="rows", help="N > 1: row slabs or (N/2) x 2 blocks")
     ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--verify", type=int, default=30, help="N > 1: iterations of the untimed cross-check against one GPU (0 = skip)")
+    ap.add_argument("--verify-max-unknowns", type=float, default=2.6e8, help="skip that cross-check above this size (host set-up time)")
+    ap.add_argument("--watchdog", type=float, default=1500.0, help="seconds after which a stuck run reports an error line and exits")
     args = ap.parse_args()
+
+    # A collective that never completes must not hang the caller for ever: report and leave.
+    import threading
+    def _expired():
+        if int(os.environ.get("RANK", "0")) == 0:
+            emit({"metric": "cg_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                  "error": f"no result after {args.watchdog:.0f} s (watchdog): the run was stuck, most likely in a collective"})
+        os._exit(3)
+    wd = threading.Timer(args.watchdog, _expired)
+    wd.daemon = True
+    wd.start()
 
     import torch
     import iterative_solvers_amd as isa
@@ -210,6 +245,7 @@ def main():
 
     if world > 1 or args.gpus > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1":
         out = bench_team(args, rule)
+        wd.cancel()
         if rank == 0:
             emit(out)
         return
@@ -284,6 +320,7 @@ def main():
     }
     if args.cpu_iters > 0 and not f32:
         out["cpu_baseline"] = cpu_baseline(n, args.cpu_iters)
+    wd.cancel()
     emit(out)
 
 
