@@ -307,7 +307,7 @@ def main():
         "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson {'fp32 inner CG of the mixed-precision path' if f32 else 'fp64'}, matrix-free CG, fixed {args.steps} iterations",
                    "n": n, "unknowns": U, "rule": args.rule, "layout": h.layout()},
         "timing": "host clock around one solve of K iterations between device synchronisations (includes the solve's initialisation pass: "
-                  "3 memsets, r = b, ||r0||, two polls ~ 0.2 ms); loop_only_* = HIP events around the K iterations on the solve stream",
+                  "one pass x = 0, r = b, z = 0, ||r0||, and the last poll ~ 0.2 ms); loop_only_* = HIP events around the K iterations on the solve stream",
         "loop_only_iters_per_sec": round(its_loop, 2) if its_loop else None,
         "loop_only_ms_per_step": round(1e3 * res.loop_seconds / args.steps, 5) if its_loop else None,
         # bytes the iteration really moves in this implementation: never above the HBM pin rate

@@ -827,6 +827,62 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
     }
 }
 
+// ---- start of a solve in one pass: x = 0, r = b, z = 0 (msg_solver.cpp:33-39, matrix_free_system.cpp:392-401), the norms of
+// r0 (and of x - u = -u) and a fresh state.  Same partial-sum layout and the same element-to-thread map as k_update with
+// init == 1, which it replaces on the fp64 grid path: 4 words per unknown instead of 6 memsets + a copy + a 6-word pass.
+template <typename T>
+struct FreshArgs {
+    long long begin, nvec;     // owned flat range in units of VEC elements
+    const T* b; T* x; T* r; T* p0; const T* u;
+    double* partB; int strideB;
+    CgState* s_out;
+};
+template <typename T, int VEC, bool HAS_U>
+__global__ __launch_bounds__(kBlock) void k_init_fresh(const FreshArgs<T> a) {
+    typedef typename VecOf<T, VEC>::type vec_t;
+    __shared__ double lds[2 * kWaves];
+    dd s_rr = dd_zero(), s_e2 = dd_zero();
+    double s_rmax = 0, s_emax = 0;
+    const long long stride = (long long)gridDim.x * kBlock;
+    const vec_t* __restrict__ B = reinterpret_cast<const vec_t*>(a.b);
+    const vec_t* __restrict__ Uu = reinterpret_cast<const vec_t*>(a.u);
+    vec_t* __restrict__ X = reinterpret_cast<vec_t*>(a.x);
+    vec_t* __restrict__ R = reinterpret_cast<vec_t*>(a.r);
+    vec_t* __restrict__ P = reinterpret_cast<vec_t*>(a.p0);
+    vec_t zero;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) zero[j] = (T)0;
+    const long long end = a.begin + a.nvec;
+    for (long long i = a.begin + (long long)blockIdx.x * kBlock + threadIdx.x; i < end; i += stride) {
+        const vec_t bv = B[i];
+        vec_t uv; if (HAS_U) uv = Uu[i];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double rd = (double)bv[j];
+            dd_acc_prod(s_rr, rd, rd);
+            s_rmax = fmax(s_rmax, fabs(rd));
+            if (HAS_U) {
+                const double ee = (double)((T)0 - uv[j]);     // error = x - u with x = 0
+                s_emax = fmax(s_emax, fabs(ee));
+                dd_acc_prod(s_e2, ee, ee);
+            }
+        }
+        X[i] = zero; R[i] = bv; P[i] = zero;
+    }
+    const dd t_rr = block_reduce_dd(s_rr, lds);
+    const double t_rmax = block_reduce<true>(s_rmax, lds);
+    double t_emax = 0; dd t_e2 = dd_zero();
+    if (HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce_dd(s_e2, lds); }
+    if (threadIdx.x == 0) {
+        const int b = blockIdx.x, st = a.strideB;
+        a.partB[FB_RR * st + b] = t_rr.hi; a.partB[(FB_RR + FB_LO) * st + b] = t_rr.lo;
+        a.partB[FB_D2 * st + b] = 0.0; a.partB[(FB_D2 + FB_LO) * st + b] = 0.0;
+        a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
+        a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = 0.0; a.partB[FB_EMAX * st + b] = t_emax;
+        if (blockIdx.x == 0) { *a.s_out = CgState{}; a.s_out->first = 1; }
+    }
+}
+
 // ---- phase B: r -= alpha * (A_h p) with A_h p rebuilt from the stored direction, x update, norms ----------------
 // This kernel walks the same (chunk, strip) items as the stencil launch -- in the opposite order and direction, so it
 // starts on the rows that launch touched last -- keeps three rows of p in registers and evaluates the 5-point formula

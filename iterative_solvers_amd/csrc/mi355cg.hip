@@ -1054,13 +1054,18 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     c->events.reset(); c->ev_pairs[0].clear(); c->ev_pairs[1].clear();
 
     // x = 0, r = b, z = 0 (the first stencil makes z = r + 0*z = r)    msg_solver.cpp:33-39
-    const size_t bytes = sizeof(double) * c->storage_len;
-    HIPCK(hipMemsetAsync(c->x, 0, bytes, c->stream));
-    for (int k = 0; k < c->xsteps; ++k) HIPCK(hipMemsetAsync(c->p[k], 0, bytes, c->stream));
-    HIPCK(hipMemsetAsync(c->ap, 0, bytes, c->stream));
-    HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
+    // One pass over the owned range.  Everything outside it (pitch padding, the rows around the grid) was zeroed when the
+    // vectors were allocated and no launch writes anything but zeros there; the other directions of the ring are written
+    // (iterations 1 .. M-1) before the folded x update first reads them (iteration M).
     c->cur = 0;
-    launch_update_flat<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, c->stream, c->whole.grid);
+    {
+        FreshArgs<double> f{};
+        f.begin = c->g.own_begin / 2; f.nvec = c->g.own_len / 2;
+        f.b = c->b; f.x = c->x; f.r = c->r; f.p0 = c->p[0]; f.u = c->u;
+        f.partB = c->partB; f.strideB = c->strideB; f.s_out = c->sB;
+        if (cfg.has_u) hipLaunchKernelGGL((k_init_fresh<double, 2, true>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
+        else hipLaunchKernelGGL((k_init_fresh<double, 2, false>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
+    }
     HIPCK(hipGetLastError());
 
     auto poll = [&]() -> int {
@@ -1070,9 +1075,13 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
         HIPCK(hipStreamSynchronize(c->stream));
         return MI355CG_OK;
     };
-    if (int rc = poll()) return rc;
-    const double initial_rnorm2 = c->summary_h->rnorm2;
-    if (msg && cb) cb(user, 0, DBL_MAX, c->summary_h->rmax, cfg.has_u ? c->summary_h->emax : DBL_MAX);   // msg_solver.cpp:75-77
+    // The state of iteration 0 is only fetched when somebody looks at it (the it = 0 callback, msg_solver.cpp:75-77);
+    // ||r0|| travels in the state and is read with the last poll.
+    *c->summary_h = CgState{};
+    if (msg && cb) {
+        if (int rc = poll()) return rc;
+        cb(user, 0, DBL_MAX, c->summary_h->rmax, cfg.has_u ? c->summary_h->emax : DBL_MAX);
+    }
     if (!c->ev_loop[0]) { HIPCK(hipEventCreate(&c->ev_loop[0])); HIPCK(hipEventCreate(&c->ev_loop[1])); }
     HIPCK(hipEventRecord(c->ev_loop[0], c->stream));
 
@@ -1196,7 +1205,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     res.final_precision = fin.it > 0 ? fin.dmax : DBL_MAX;
     res.final_error_norm = cfg.has_u ? fin.emax : DBL_MAX;
     res.r_norm2 = fin.rnorm2;
-    res.initial_r_norm2 = initial_rnorm2;
+    res.initial_r_norm2 = fin.r0norm;
     res.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     { float ms = 0; HIPCK(hipEventSynchronize(c->ev_loop[1])); if (hipEventElapsedTime(&ms, c->ev_loop[0], c->ev_loop[1]) == hipSuccess) res.loop_seconds = 1e-3 * ms; }
     if (msg && cb) cb(user, res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm);   // msg_solver.cpp:193-195
