@@ -418,12 +418,18 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
         c->events.reset(); c->ev_pairs[0].clear(); c->ev_pairs[1].clear(); p.comm_pairs.clear();
         c->profiling = t->profiling;
-        const size_t bytes = sizeof(double) * c->storage_len;
-        HIPCK(hipMemsetAsync(c->x, 0, bytes, c->stream));
-        for (int k = 0; k < c->xsteps; ++k) HIPCK(hipMemsetAsync(c->p[k], 0, bytes, c->stream));
-        HIPCK(hipMemcpyAsync(c->r, c->b, bytes, hipMemcpyDeviceToDevice, c->stream));
+        // one pass over the owned range (mi355cg_solve does the same); the ghost cells of the first direction are zeroed too:
+        // they still hold the neighbours' last direction of the previous solve
+        HIPCK(hipMemsetAsync(c->p[0], 0, sizeof(double) * c->storage_len, c->stream));
         c->cur = 0;
-        launch_update_flat<double, 2>(c, cfg, c->x, c->r, c->p[0], c->ap, c->u, c->stream, c->whole.grid);
+        {
+            FreshArgs<double> f{};
+            f.begin = c->g.own_begin / 2; f.nvec = c->g.own_len / 2;
+            f.b = c->b; f.x = c->x; f.r = c->r; f.p0 = c->p[0]; f.u = c->u;
+            f.partB = c->partB; f.strideB = c->strideB; f.s_out = c->sB;
+            if (cfg.has_u) hipLaunchKernelGGL((k_init_fresh<double, 2, true>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
+            else hipLaunchKernelGGL((k_init_fresh<double, 2, false>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
+        }
         if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
         HIPCK(hipEventRecord(p.ev_redge, c->stream));
         team_record(t, p, 1, c->whole.grid);
@@ -447,9 +453,11 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         HIPCK(hipStreamSynchronize(lead.c->stream));
         return MI355CG_OK;
     };
-    if (int rc = poll()) return rc;
-    const double initial_rnorm2 = lead.c->summary_h->rnorm2;
-    if (msg && cb) cb(user, 0, DBL_MAX, lead.c->summary_h->rmax, cfg.has_u ? lead.c->summary_h->emax : DBL_MAX);
+    *lead.c->summary_h = CgState{};
+    if (msg && cb) {                       // the state of iteration 0 is only fetched for its callback (msg_solver.cpp:75-77)
+        if (int rc = poll()) return rc;
+        cb(user, 0, DBL_MAX, lead.c->summary_h->rmax, cfg.has_u ? lead.c->summary_h->emax : DBL_MAX);
+    }
 
     const int every = prm->callback_every;
     int sync_every = std::min(prm->sync_every > 0 ? prm->sync_every : (msg ? 100 : 200), kHist);
@@ -561,7 +569,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     res.final_residual_norm = fin.rmax;
     res.final_precision = fin.it > 0 ? fin.dmax : DBL_MAX;
     res.final_error_norm = cfg.has_u ? fin.emax : DBL_MAX;
-    res.r_norm2 = fin.rnorm2; res.initial_r_norm2 = initial_rnorm2;
+    res.r_norm2 = fin.rnorm2; res.initial_r_norm2 = fin.r0norm;
     res.solve_seconds = wall;
     { float ms = 0; if (hipEventElapsedTime(&ms, lead.c->ev_loop[0], lead.c->ev_loop[1]) == hipSuccess) res.loop_seconds = 1e-3 * ms; }
     if (msg && cb) cb(user, res.iterations, res.final_precision, res.final_residual_norm, res.final_error_norm);

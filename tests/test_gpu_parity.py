@@ -556,3 +556,23 @@ def test_n4096_converged_against_the_oracle(isa):
         assert np.abs(np.array([c[2] for c in cbs]) - np.array([c[2] for c in mr["callbacks"]])).max() / mf["initial_r_norm"] <= 1e-10
         xs = np.array([float.fromhex(h) for h in mr["x"]["hex"]])
         assert np.abs(xm[::mr["x"]["stride"]] - xs).max() <= 1e-9 * np.abs(xs).max()
+
+
+def test_a_solve_does_not_depend_on_what_the_previous_one_left_behind(isa):
+    """The start of a solve rewrites only the owned range of x, r and the first direction (k_init_fresh): everything a launch
+    reads beyond that has to be independent of the previous solve -- 7 iterations of one rule, then a full solve of the other,
+    against a fresh context."""
+    from iterative_solvers_amd import _capi
+    n = 258
+    fresh = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0)
+    used = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0)
+    for first, second in ((_capi.RULE_REL_2NORM, _capi.RULE_MSG_MAXNORM), (_capi.RULE_MSG_MAXNORM, _capi.RULE_REL_2NORM)):
+        p = isa.default_params(first)
+        p.max_iterations, p.eps_rel, p.eps_precision, p.eps_residual = 7, 1e-30, 1e-30, 1e-30
+        used._handle.solve(p)
+        q = isa.default_params(second)
+        q.max_iterations, q.eps_rel, q.eps_precision, q.eps_residual, q.eps_exact_error = 10 ** 5, 1e-8, 1e-9, 1e-9, -1.0
+        a, b = fresh._handle.solve(q), used._handle.solve(q)
+        assert (a.iterations, a.stop_reason, a.r_norm2, a.initial_r_norm2, a.final_precision) == (b.iterations, b.stop_reason, b.r_norm2, b.initial_r_norm2, b.final_precision)
+        assert np.array_equal(fresh._handle.solution(), used._handle.solution())
+        assert np.array_equal(fresh._handle.recursive_residual(), used._handle.recursive_residual())
