@@ -41,7 +41,7 @@ stats = glob.glob(f"{P}_kt/**/*kernel_stats.csv", recursive=True)
 if stats:
     shutil.copy(sorted(stats)[-1], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_n{grid}.csv"))
 o = j["roofline"]["other"]
-hdr = f"""rocprofv3 summary ({tag}), default path: REL_2NORM, A p recomputed in the update launch, x updated every second iteration
+hdr = f"""rocprofv3 summary ({tag}), default path: REL_2NORM, A p recomputed in the update launch, x updated every fourth iteration
 ({j['roofline']['words_per_unknown_per_iteration']} words/unknown/iteration); double-double inner products; buffer-resource addressing; fetch cursor running
 ahead of the compute cursor across work items; launch geometry {j['config']['layout']}.
 Commands (on the MI355X box, from /tmp with TMPDIR=/tmp, see tools/profile_gpu.sh {grid}):
@@ -51,7 +51,7 @@ Workload: N={grid} (U={U} unknowns), fp64, fixed-iteration CG.
 Un-profiled bench of the same build on the same box: {j['value']} it/s wall ({j.get('loop_only_iters_per_sec')} it/s by HIP events around the iterations alone),
 {j['hbm_gbps']} GB/s really moved (profiles/{tag}_bench_n{grid}.json); HIP-event per-launch means in that bench:
 k_stencil {o['stencil']['avg_ms']} ms = {o['stencil']['achieved']} GB/s, k_update_st {o['update']['avg_ms']} ms = {o['update']['achieved']} GB/s
-(k_update_st alternates between 3-word launches on odd iterations and 6-word launches on even ones; the figures are means over both).
+(k_update_st: 3-word launches on three iterations of four, an 8-word launch on the fourth; the figures are means over all).
 
 == kernel trace (--kernel-trace --stats) ==
 """
