@@ -25,12 +25,25 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libmi355cg.so cannot be built (there is no CPU fallback)")
 
 
+STAMP_PATH = LIB_PATH + ".srchash"
+
+
+def _source_hash() -> str:
+    """Contents of everything the library is built from (not modification times: a copy of the tree, e.g. the snapshot
+    sent to a GPU box, need not keep them in order)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP_PATH) as fh:
+        return fh.read().strip() != _source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -43,8 +56,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     try:
+        stamp = _source_hash()                      # of what the compiler is about to read
         subprocess.check_call(cmd, cwd=CSRC)
         os.replace(tmp, LIB_PATH)
+        with open(f"{STAMP_PATH}.tmp.{os.getpid()}", "w") as fh:
+            fh.write(stamp + "\n")
+        os.replace(f"{STAMP_PATH}.tmp.{os.getpid()}", STAMP_PATH)
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
