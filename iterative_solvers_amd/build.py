@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libmi355cg.so")
 SOURCES = ["mi355cg.hip", "grid_setup.cpp"]
 HEADERS = ["cg_kernels.h", "csr_kernels.h", "team.h", "grid_setup.h", os.path.join("..", "..", "include", "mi355cg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wno-unused-value", "-Wno-unused-result", "-pthread"]
 
 
 def _hipcc() -> str:

@@ -25,6 +25,12 @@
 // Sums travel as double-double pairs and are reduced in part order by every consumer, so every decomposition takes
 // bit-identical steps (tests/test_gpu_team.py).
 #include <dlfcn.h>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <rccl/rccl.h>        // types and constants only: every RCCL function is resolved with dlsym
 
 namespace {
@@ -330,6 +336,7 @@ int team_exchange_records(mi355cg_team_s* t, int which) {
     return MI355CG_OK;
 }
 
+int part_halo_in(mi355cg_team_s* t, TeamPart& p);
 // boundary rows / columns of r to the neighbours; ev_halo of every part fires when its ghost cells are in place
 int team_exchange_halo(mi355cg_team_s* t) {
     if (t->rccl) {
@@ -357,25 +364,7 @@ int team_exchange_halo(mi355cg_team_s* t) {
         HIPCK(hipGetLastError());
         return MI355CG_OK;
     }
-    for (auto& p : t->parts) {                                       // p = destination
-        HIPCK(hipSetDevice(p.c->device));
-        int last_src = -1;
-        for (size_t i = 0; i < p.recvs.size(); ++i) {
-            const Seg& s = p.recvs[i];
-            TeamPart* q = nullptr;
-            for (auto& o : t->parts) if (o.rank == s.src) q = &o;
-            if (!q) return fail(MI355CG_ERR_STATE, "part %d is not in this process", s.src);
-            if (s.src != last_src) { HIPCK(hipStreamWaitEvent(p.comm, q->ev_redge, 0)); last_src = s.src; }
-            const double* src = nullptr;
-            if (s.kind == 0) src = seg_ptr(q->c, q->c->r, s);
-            else for (size_t j = 0; j < q->sends.size(); ++j) if (q->sends[j].id == s.id) src = q->send_cols + q->send_off[j];
-            double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
-            HIPCK(hipMemcpyAsync(dst, src, sizeof(double) * seg_count(s), hipMemcpyDefault, p.comm));
-        }
-        if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, p.comm, a); }
-        HIPCK(hipEventRecord(p.ev_halo, p.comm));
-        HIPCK(hipGetLastError());
-    }
+    for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_halo_in(t, p)) return rc; }      // p = destination
     return MI355CG_OK;
 }
 
@@ -399,6 +388,158 @@ void team_record(mi355cg_team_s* t, TeamPart& p, int which, int nslots) {
     hipLaunchKernelGGL(k_team_record, dim3(1), dim3(kBlock), 0, c->stream, a);
     if (!t->rccl) hipEventRecord(which == 0 ? p.ev_recA : p.ev_recB, c->stream);
 }
+
+PartSrc team_gsrc(const mi355cg_team_s* t, TeamPart& p, int which) { return PartSrc{which == 0 ? p.gA : p.gB, t->world, 1, kRecHeader}; }
+
+// ---- one part's share of an iteration (called by the one driving thread, or by the part's own thread) --------------
+// stencil phase: the launch that ends it writes the part's record (its last block)
+int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
+    mi355cg_ctx* c = p.c;
+    hipEvent_t e0 = nullptr;
+    prof_begin(c, &e0);
+    if (p.split) {
+        const RecSpec rs = team_rec_spec(t, p, 0, c->interior.grid + c->edge.grid);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 1));
+        prof_end(c, 0, e0);
+        HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
+        prof_begin(c, &e0);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 1), &rs);
+    } else {
+        const RecSpec rs = team_rec_spec(t, p, 0, c->whole.grid);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), team_gsrc(t, p, 1), &rs);
+    }
+    prof_end(c, 0, e0);
+    c->cur = (c->cur + 1) % c->xsteps;
+    if (!t->rccl) HIPCK(hipEventRecord(p.ev_recA, c->stream));
+    return MI355CG_OK;
+}
+// update phase: edge items first, so the halo of r is on its way while the interior is updated
+int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
+    mi355cg_ctx* c = p.c;
+    hipEvent_t e0 = nullptr;
+    prof_begin(c, &e0);
+    if (p.split) {
+        const RecSpec rs = team_rec_spec(t, p, 1, c->interior.grid + c->edge.grid);
+        const bool has_int = c->interior.wl.nitems > 0;
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 0), has_int ? nullptr : &rs);
+        if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
+        prof_end(c, 1, e0);
+        HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        prof_begin(c, &e0);
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 0), &rs);
+    } else {
+        const RecSpec rs = team_rec_spec(t, p, 1, c->whole.grid);
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0), &rs);
+        HIPCK(hipEventRecord(p.ev_redge, c->stream));
+    }
+    prof_end(c, 1, e0);
+    if (!t->rccl) HIPCK(hipEventRecord(p.ev_recB, c->stream));
+    HIPCK(hipGetLastError());
+    return MI355CG_OK;
+}
+// LOCAL: fetch this part's incoming halo segments (device-to-device copies on its comm stream); ev_halo fires when they are in place
+int part_halo_in(mi355cg_team_s* t, TeamPart& p) {
+    int last_src = -1;
+    for (size_t i = 0; i < p.recvs.size(); ++i) {
+        const Seg& s = p.recvs[i];
+        TeamPart* q = nullptr;
+        for (auto& o : t->parts) if (o.rank == s.src) q = &o;
+        if (!q) return fail(MI355CG_ERR_STATE, "part %d is not in this process", s.src);
+        if (s.src != last_src) { HIPCK(hipStreamWaitEvent(p.comm, q->ev_redge, 0)); last_src = s.src; }
+        const double* src = nullptr;
+        if (s.kind == 0) src = seg_ptr(q->c, q->c->r, s);
+        else for (size_t j = 0; j < q->sends.size(); ++j) if (q->sends[j].id == s.id) src = q->send_cols + q->send_off[j];
+        double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
+        HIPCK(hipMemcpyAsync(dst, src, sizeof(double) * seg_count(s), hipMemcpyDefault, p.comm));
+    }
+    if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, p.comm, a); }
+    HIPCK(hipEventRecord(p.ev_halo, p.comm));
+    HIPCK(hipGetLastError());
+    return MI355CG_OK;
+}
+// the decision of the last iteration, for the host (every part evaluates it: all parts hold the same records)
+int part_poll_enqueue(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
+    launch_check(p.c, cfg, p.c->stream, team_gsrc(t, p, 1));
+    hipLaunchKernelGGL(k_team_stop, dim3(1), dim3(64), 0, p.c->stream, p.gB, t->world, p.c->summary);
+    return MI355CG_OK;
+}
+
+// ---- LOCAL transport with one host thread per part -------------------------------------------------------------------
+// One thread issues ~20 runtime calls per part and iteration; with the parts on 8 different GPUs that is the host, not the GPUs,
+// setting the pace.  Here every part has its own thread; the threads meet at two barriers per
+// iteration, each right after the events the other parts are about to wait on have been recorded (an event has to be
+// RECORDED before another thread may enqueue a wait on it).  Everything between the barriers is the part's own stream work.
+struct TeamCrew {
+    mi355cg_team_s* t = nullptr;
+    IterCfg cfg{};
+    int nthreads = 0;
+    std::atomic<int> arrived{0}, generation{0};
+    std::atomic<int> error{0};
+    std::string error_text;
+    std::mutex mu;                       // chunk hand-over (workers sleep between chunks: the host waits for the device there)
+    std::condition_variable cv;
+    int chunk_seq = 0, chunk_m = 0, done_count = 0;
+    bool chunk_poll = false, quit = false;
+
+    void note_error(int rc) { int zero = 0; if (error.compare_exchange_strong(zero, rc)) { std::lock_guard<std::mutex> g(mu); error_text = g_err; } }
+    // spinning barrier for the two meeting points inside an iteration (microseconds apart); gives way when there are more
+    // threads than cores; returns false once any thread has failed
+    bool barrier() {
+        const int gen = generation.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) == nthreads - 1) {
+            arrived.store(0, std::memory_order_relaxed);
+            generation.store(gen + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (generation.load(std::memory_order_acquire) == gen) {
+                if (error.load(std::memory_order_relaxed)) return false;
+                if (++spins > 256) { std::this_thread::yield(); spins = 0; }
+            }
+        }
+        return error.load(std::memory_order_relaxed) == 0;
+    }
+    // the iterations of one chunk as seen by part i
+    int run_chunk(int i, int m, bool poll) {
+        TeamPart& p = t->parts[i];
+        for (int k = 0; k < m; ++k) {
+            if (int rc = part_stencil_phase(t, p, cfg)) return rc;
+            if (!barrier()) return MI355CG_ERR_STATE;
+            for (auto& q : t->parts) if (&q != &p) HIPCK(hipStreamWaitEvent(p.c->stream, q.ev_recA, 0));
+            if (int rc = part_update_phase(t, p, cfg)) return rc;
+            if (!barrier()) return MI355CG_ERR_STATE;
+            if (int rc = part_halo_in(t, p)) return rc;
+            for (auto& q : t->parts) if (&q != &p) HIPCK(hipStreamWaitEvent(p.c->stream, q.ev_recB, 0));
+        }
+        if (poll) if (int rc = part_poll_enqueue(t, p, cfg)) return rc;
+        return MI355CG_OK;
+    }
+    void worker(int i) {
+        if (hipSetDevice(t->parts[i].c->device) != hipSuccess) { fail(MI355CG_ERR_HIP, "hipSetDevice failed in a team thread"); note_error(MI355CG_ERR_HIP); }
+        int seen = 0;
+        for (;;) {
+            int m; bool poll;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return quit || chunk_seq != seen; });
+                if (quit) return;
+                seen = chunk_seq; m = chunk_m; poll = chunk_poll;
+            }
+            if (!error.load()) if (int rc = run_chunk(i, m, poll)) { if (rc != MI355CG_ERR_STATE || !error.load()) note_error(rc); }
+            { std::lock_guard<std::mutex> g(mu); ++done_count; }
+            cv.notify_all();
+        }
+    }
+    // called by the solving thread (which is part 0's thread): run m iterations on every part, return when all are enqueued
+    int chunk(int m, bool poll) {
+        { std::lock_guard<std::mutex> g(mu); chunk_m = m; chunk_poll = poll; done_count = 0; ++chunk_seq; }
+        cv.notify_all();
+        if (hipSetDevice(t->parts[0].c->device) != hipSuccess) { fail(MI355CG_ERR_HIP, "hipSetDevice failed"); note_error(MI355CG_ERR_HIP); }
+        if (!error.load()) if (int rc = run_chunk(0, m, poll)) { if (rc != MI355CG_ERR_STATE || !error.load()) note_error(rc); }
+        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return done_count == nthreads - 1; }); }
+        if (const int rc = error.load()) { g_err = error_text; return rc; }
+        return MI355CG_OK;
+    }
+};
 
 int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
                const volatile int* stop_flag, mi355cg_results* out) {
@@ -440,12 +581,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     if (int rc = team_exchange_records(t, 1)) return rc;
 
     TeamPart& lead = t->parts[0];
-    auto poll = [&]() -> int {
-        for (auto& p : t->parts) {
-            HIPCK(hipSetDevice(p.c->device));
-            launch_check(p.c, cfg, p.c->stream, gsrc(p, 1));
-            hipLaunchKernelGGL(k_team_stop, dim3(1), dim3(64), 0, p.c->stream, p.gB, W, p.c->summary);
-        }
+    auto poll_fetch = [&]() -> int {
         HIPCK(hipSetDevice(lead.c->device));
         HIPCK(hipMemcpyAsync(lead.c->summary_h, lead.c->summary, sizeof(CgState), hipMemcpyDeviceToHost, lead.c->stream));
         HIPCK(hipMemcpyAsync(lead.c->hist_h, lead.c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, lead.c->stream));
@@ -453,6 +589,31 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         HIPCK(hipStreamSynchronize(lead.c->stream));
         return MI355CG_OK;
     };
+    auto poll = [&]() -> int {
+        for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_poll_enqueue(t, p, cfg)) return rc; }
+        return poll_fetch();
+    };
+    // LOCAL transport with several parts: one thread per part (MI355CG_TEAM_THREADS=0: the one-thread loop)
+    std::unique_ptr<TeamCrew> crew;
+    std::vector<std::thread> crew_threads;
+    auto stop_crew = [&]() {
+        if (!crew) return;
+        { std::lock_guard<std::mutex> g(crew->mu); crew->quit = true; }
+        crew->cv.notify_all();
+        for (auto& th : crew_threads) th.join();
+        crew_threads.clear(); crew.reset();
+    };
+    struct CrewGuard { std::function<void()> f; ~CrewGuard() { f(); } } crew_guard{stop_crew};      // every way out joins the threads
+    // Default: threads when the parts live on different GPUs.  Parts sharing ONE GPU (the rehearsals of tests/ and tools/) gain
+    // nothing -- their launches queue up on the same device whoever issues them (measured: 0.45 vs 0.42 ms per iteration with 4
+    // parts of N = 4096, 0.77 vs 0.59 with 8) -- so they keep the one-thread loop.  MI355CG_TEAM_THREADS=0 | 1 overrides.
+    bool several_devices = false;
+    for (auto& p : t->parts) if (p.c->device != t->parts[0].c->device) several_devices = true;
+    if (!t->rccl && t->parts.size() > 1 && env_int("MI355CG_TEAM_THREADS", several_devices ? 1 : 0) != 0) {
+        crew.reset(new TeamCrew);
+        crew->t = t; crew->cfg = cfg; crew->nthreads = (int)t->parts.size();
+        for (int i = 1; i < crew->nthreads; ++i) crew_threads.emplace_back([&, i] { crew->worker(i); });
+    }
     *lead.c->summary_h = CgState{};
     if (msg && cb) {                       // the state of iteration 0 is only fetched for its callback (msg_solver.cpp:75-77)
         if (int rc = poll()) return rc;
@@ -478,57 +639,19 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         if (msg && every > 0) m = std::min(m, every - it_done % every);
         if (first_chunk || want_stop) { m = 1; first_chunk = false; }
         if (m <= 0) m = 1;
-        for (int k = 0; k < m; ++k) {
-            // ---- stencil phase: the launch that ends it writes the part's record (its last block) ----
-            for (auto& p : t->parts) {
-                mi355cg_ctx* c = p.c;
-                HIPCK(hipSetDevice(c->device));
-                hipEvent_t e0 = nullptr;
-                prof_begin(c, &e0);
-                if (p.split) {
-                    const RecSpec rs = team_rec_spec(t, p, 0, c->interior.grid + c->edge.grid);
-                    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, gsrc(p, 1));
-                    prof_end(c, 0, e0);
-                    HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
-                    prof_begin(c, &e0);
-                    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, gsrc(p, 1), &rs);
-                } else {
-                    const RecSpec rs = team_rec_spec(t, p, 0, c->whole.grid);
-                    launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), gsrc(p, 1), &rs);
-                }
-                prof_end(c, 0, e0);
-                c->cur = (c->cur + 1) % c->xsteps;
-                if (!t->rccl) HIPCK(hipEventRecord(p.ev_recA, c->stream));
+        if (crew) {
+            if (int rc = crew->chunk(m, true)) return rc;
+            if (int rc = poll_fetch()) return rc;
+        } else {
+            for (int k = 0; k < m; ++k) {
+                for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_stencil_phase(t, p, cfg)) return rc; }
+                if (int rc = team_exchange_records(t, 0)) return rc;
+                for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_update_phase(t, p, cfg)) return rc; }
+                if (int rc = team_exchange_halo(t)) return rc;
+                if (int rc = team_exchange_records(t, 1)) return rc;
             }
-            if (int rc = team_exchange_records(t, 0)) return rc;
-            // ---- update phase: edge items first, so the halo of r is on its way while the interior is updated ----
-            for (auto& p : t->parts) {
-                mi355cg_ctx* c = p.c;
-                HIPCK(hipSetDevice(c->device));
-                hipEvent_t e0 = nullptr;
-                prof_begin(c, &e0);
-                if (p.split) {
-                    const RecSpec rs = team_rec_spec(t, p, 1, c->interior.grid + c->edge.grid);
-                    const bool has_int = c->interior.wl.nitems > 0;
-                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, gsrc(p, 0), has_int ? nullptr : &rs);
-                    if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
-                    prof_end(c, 1, e0);
-                    HIPCK(hipEventRecord(p.ev_redge, c->stream));
-                    prof_begin(c, &e0);
-                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, gsrc(p, 0), &rs);
-                } else {
-                    const RecSpec rs = team_rec_spec(t, p, 1, c->whole.grid);
-                    launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), gsrc(p, 0), &rs);
-                    HIPCK(hipEventRecord(p.ev_redge, c->stream));
-                }
-                prof_end(c, 1, e0);
-                if (!t->rccl) HIPCK(hipEventRecord(p.ev_recB, c->stream));
-                HIPCK(hipGetLastError());
-            }
-            if (int rc = team_exchange_halo(t)) return rc;
-            if (int rc = team_exchange_records(t, 1)) return rc;
+            if (int rc = poll()) return rc;
         }
-        if (int rc = poll()) return rc;
         const int it_now = lead.c->summary_h->it;
         if (msg && cb) for (int it = it_done + 1; it <= it_now; ++it) {
             const bool stopped_here = lead.c->summary_h->done && lead.c->summary_h->reason != MI355CG_STOP_ITERATIONS && it == it_now;

@@ -84,6 +84,32 @@ def test_local_team_msg_rule_callbacks_and_stop_reason(n, world, decomp):
     t.close()
 
 
+@pytest.mark.parametrize("n,world,decomp", [(258, 4, 1), (130, 3, 0), (66, 16, 0)])
+def test_local_team_with_one_thread_per_part(n, world, decomp, monkeypatch):
+    """The multi-GPU form of the LOCAL transport (a host thread per part, two barriers per iteration), forced on for parts that
+    share the test box's one GPU: same bits as the one-thread loop and as the single context, both rules, 16 threads on few cores."""
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    monkeypatch.setenv("MI355CG_TEAM_THREADS", "1")
+    kw = dict(eps_rel=1e-8, max_iterations=10 ** 5)
+    s1, r1, _ = _single(isa, n, 1, **kw)
+    t = Team.local(n, world, decomp)
+    rt = t.solve(_params(isa, 1, **kw))
+    assert (rt.iterations, rt.r_norm2, rt.initial_r_norm2) == (r1.iterations, r1.r_norm2, r1.initial_r_norm2)
+    assert np.array_equal(t.vector(0), s1._handle.solution())
+    kw = dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iterations=10 ** 5)
+    s0, r0, cb0 = _single(isa, n, 0, **kw)
+    cbs = []
+    rm = t.solve(_params(isa, 0, **kw), callback=lambda *a: cbs.append(a))
+    assert (rm.iterations, rm.stop_reason, rm.final_residual_norm, rm.final_precision) == (r0.iterations, r0.stop_reason, r0.final_residual_norm, r0.final_precision)
+    assert cbs == cb0 and np.array_equal(t.vector(0), s0._handle.solution())
+    stop = C.c_int(0)
+    seen = []
+    rs = t.solve(_params(isa, 0, **kw), callback=lambda it, *a: (seen.append(it), stop.__setattr__("value", 1 if it >= 1 else 0)), stop_flag=stop)
+    assert rs.stop_reason == 4 and rs.iterations == 1                   # INTERRUPTED right after the it = 1 callback
+    t.close()
+
+
 def test_team_stop_request_and_iteration_cap():
     import iterative_solvers_amd as isa
     from iterative_solvers_amd.distributed import Team
