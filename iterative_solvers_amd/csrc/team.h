@@ -230,6 +230,12 @@ struct mi355cg_team_s {
     hipStream_t hub = nullptr;              // LOCAL: joins the parts' record events
     hipEvent_t ev_hub = nullptr;
     int* stop_h = nullptr;                  // pinned: this process's stop request, read by k_team_record
+    // Interior / edge launches per phase (the halo travels while the interior items run) or ONE launch per phase (the halo
+    // travels while the update records are all-gathered).  See team_solve; MI355CG_TEAM_SPLIT=1 selects the former.
+    bool split_phases = false;
+    // RCCL: the halo group on the COMPUTE stream, between the update launch and the all-gather of its records (no second
+    // stream, no events), instead of on the comm stream beside them.  MI355CG_TEAM_HALO_INLINE.
+    bool halo_inline = false;
     bool profiling = false;
     double prof_kernel_ms = 0, prof_comm_ms = 0, prof_wall_ms = 0;     // per iteration, last profiled solve
     int hub_device = 0;
@@ -262,13 +268,19 @@ void team_free(mi355cg_team_s* t) {
 // Per-part resources and halo lists once the contexts exist.
 int team_finish_setup(mi355cg_team_s* t) {
     t->segs = halo_segments(t->gp, t->boxes);
+    // Events that only order streams of ONE device need no system-scope fence (a default event writes back and invalidates the
+    // caches when it fires: ~10 us on the compute stream between two launches).  Parts on several GPUs read each other's rows
+    // after these events: those keep the default.
+    bool one_device = true;
+    for (auto& p : t->parts) if (p.c->device != t->parts[0].c->device) one_device = false;
+    const unsigned ev_flags = hipEventDisableTiming | (one_device && env_int("MI355CG_TEAM_EVENT_FENCE", 0) == 0 ? hipEventDisableSystemFence : 0u);
     for (auto& p : t->parts) {
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
         HIPCK(hipStreamCreateWithFlags(&p.comm, hipStreamNonBlocking));
         if (int rc = alloc_vec(&p.gA, (long long)t->world * kRecHeader)) return rc;
         if (int rc = alloc_vec(&p.gB, (long long)t->world * kRecHeader)) return rc;
-        for (hipEvent_t* e : {&p.ev_recA, &p.ev_gA, &p.ev_redge, &p.ev_recB, &p.ev_gB, &p.ev_halo}) HIPCK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&p.ev_recA, &p.ev_gA, &p.ev_redge, &p.ev_recB, &p.ev_gB, &p.ev_halo}) HIPCK(hipEventCreateWithFlags(e, ev_flags));
         for (auto& s : t->segs) { if (s.src == p.rank) p.sends.push_back(s); if (s.dst == p.rank) p.recvs.push_back(s); }
         auto by_peer = [](bool send) { return [send](const Seg& a, const Seg& b) { const int pa = send ? a.dst : a.src, pb = send ? b.dst : b.src; return pa != pb ? pa < pb : a.id < b.id; }; };
         std::sort(p.sends.begin(), p.sends.end(), by_peer(true));
@@ -297,7 +309,7 @@ int team_finish_setup(mi355cg_team_s* t) {
         t->hub_device = t->parts[0].c->device;
         HIPCK(hipSetDevice(t->hub_device));
         HIPCK(hipStreamCreateWithFlags(&t->hub, hipStreamNonBlocking));
-        HIPCK(hipEventCreateWithFlags(&t->ev_hub, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&t->ev_hub, ev_flags));
         // parts on different GPUs of one process reach each other's memory directly (xGMI peer access)
         for (auto& a : t->parts) for (auto& b : t->parts) if (a.c->device != b.c->device) {
             int can = 0;
@@ -341,26 +353,27 @@ int part_halo_in(mi355cg_team_s* t, TeamPart& p);
 int team_exchange_halo(mi355cg_team_s* t) {
     if (t->rccl) {
         TeamPart& p = t->parts[0];
-        HIPCK(hipStreamWaitEvent(p.comm, p.ev_redge, 0));
+        const hipStream_t hs = t->halo_inline ? p.c->stream : p.comm;
+        if (!t->halo_inline) HIPCK(hipStreamWaitEvent(p.comm, p.ev_redge, 0));
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.comm); }
+        if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, hs); }
         if (!p.sends.empty() || !p.recvs.empty()) {
             NCCLCK(rccl_api()->GroupStart());
             for (size_t i = 0; i < p.sends.size(); ++i) {
                 const Seg& s = p.sends[i];
                 const double* src = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.send_cols + p.send_off[i];
-                NCCLCK(rccl_api()->Send(src, (size_t)seg_count(s), ncclDouble, s.dst, t->comm_halo, p.comm));
+                NCCLCK(rccl_api()->Send(src, (size_t)seg_count(s), ncclDouble, s.dst, t->comm_halo, hs));
             }
             for (size_t i = 0; i < p.recvs.size(); ++i) {
                 const Seg& s = p.recvs[i];
                 double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
-                NCCLCK(rccl_api()->Recv(dst, (size_t)seg_count(s), ncclDouble, s.src, t->comm_halo, p.comm));
+                NCCLCK(rccl_api()->Recv(dst, (size_t)seg_count(s), ncclDouble, s.src, t->comm_halo, hs));
             }
             NCCLCK(rccl_api()->GroupEnd());
-            if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, p.comm, a); }
+            if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, hs, a); }
         }
-        if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.comm); p.comm_pairs.push_back({e0, e1}); } }
-        HIPCK(hipEventRecord(p.ev_halo, p.comm));
+        if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, hs); p.comm_pairs.push_back({e0, e1}); } }
+        if (!t->halo_inline) HIPCK(hipEventRecord(p.ev_halo, p.comm));
         HIPCK(hipGetLastError());
         return MI355CG_OK;
     }
@@ -396,8 +409,9 @@ PartSrc team_gsrc(const mi355cg_team_s* t, TeamPart& p, int which) { return Part
 int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
+    if (p.split && !t->split_phases && !t->halo_inline) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));      // one launch: the halo has to be there first
     prof_begin(c, &e0);
-    if (p.split) {
+    if (p.split && t->split_phases) {
         const RecSpec rs = team_rec_spec(t, p, 0, c->interior.grid + c->edge.grid);
         launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 1));
         prof_end(c, 0, e0);
@@ -418,7 +432,7 @@ int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
     prof_begin(c, &e0);
-    if (p.split) {
+    if (p.split && t->split_phases) {
         const RecSpec rs = team_rec_spec(t, p, 1, c->interior.grid + c->edge.grid);
         const bool has_int = c->interior.wl.nitems > 0;
         launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 0), has_int ? nullptr : &rs);
@@ -430,7 +444,8 @@ int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
     } else {
         const RecSpec rs = team_rec_spec(t, p, 1, c->whole.grid);
         launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0), &rs);
-        HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
+        if (!t->halo_inline) HIPCK(hipEventRecord(p.ev_redge, c->stream));
     }
     prof_end(c, 1, e0);
     if (!t->rccl) HIPCK(hipEventRecord(p.ev_recB, c->stream));
@@ -550,7 +565,8 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     const int W = t->world;
     const auto t0 = std::chrono::steady_clock::now();
     *t->stop_h = 0;
-    auto gsrc = [&](TeamPart& p, int which) { return PartSrc{which == 0 ? p.gA : p.gB, W, 1, kRecHeader}; };
+    t->split_phases = env_int("MI355CG_TEAM_SPLIT", 0) != 0;
+    t->halo_inline = t->rccl && !t->split_phases && env_int("MI355CG_TEAM_HALO_INLINE", 0) != 0;
 
     // x = 0, r = b, z = 0; partial norms of r0; first record + halo of r0 = b
     for (auto& p : t->parts) {
@@ -572,7 +588,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
             else hipLaunchKernelGGL((k_init_fresh<double, 2, false>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
         }
         if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
-        HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        if (!t->halo_inline) HIPCK(hipEventRecord(p.ev_redge, c->stream));
         team_record(t, p, 1, c->whole.grid);
         HIPCK(hipGetLastError());
         c->solved = true;
@@ -666,7 +682,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     for (auto& p : t->parts) {
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
-        HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));           // the last halo exchange writes this part's ghost cells
+        if (!t->halo_inline) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));           // the last halo exchange writes this part's ghost cells
         c->cur = fin.it % c->xsteps;
         if (cfg.x2) launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, c->stream);
         HIPCK(hipGetLastError());

@@ -110,6 +110,24 @@ def test_local_team_with_one_thread_per_part(n, world, decomp, monkeypatch):
     t.close()
 
 
+@pytest.mark.parametrize("n,world,decomp", [(258, 4, 1), (130, 3, 0)])
+def test_team_with_interior_and_edge_launches(n, world, decomp, monkeypatch):
+    """MI355CG_TEAM_SPLIT=1: the phases as interior + edge launches (the halo travels beside the interior items) instead of the
+    default one launch per phase.  Same bits."""
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    monkeypatch.setenv("MI355CG_TEAM_SPLIT", "1")
+    for rule, kw in ((1, dict(eps_rel=1e-8, max_iterations=10 ** 5)),
+                     (0, dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iterations=10 ** 5))):
+        s1, r1, cb1 = _single(isa, n, rule, **kw)
+        t = Team.local(n, world, decomp)
+        cbs = []
+        rt = t.solve(_params(isa, rule, **kw), callback=(lambda *a: cbs.append(a)) if rule == 0 else None)
+        assert (rt.iterations, rt.stop_reason, rt.r_norm2) == (r1.iterations, r1.stop_reason, r1.r_norm2) and cbs == cb1
+        assert np.array_equal(t.vector(0), s1._handle.solution()) and np.array_equal(t.vector(1), s1._handle.recursive_residual())
+        t.close()
+
+
 def test_team_stop_request_and_iteration_cap():
     import iterative_solvers_amd as isa
     from iterative_solvers_amd.distributed import Team
@@ -141,9 +159,13 @@ def test_rccl_team_of_one_rank_runs_the_collectives():
     try:
         t = Team.rccl(n, device=0)
         rt = t.solve(_params(isa, 1, **kw))
+        os.environ["MI355CG_TEAM_HALO_INLINE"] = "1"                # the halo group on the compute stream (no events)
+        rt2 = t.solve(_params(isa, 1, **kw))
     finally:
         os.environ.pop("MI355CG_FORCE_COLLECTIVES", None)
-    assert (rt.iterations, rt.r_norm2) == (r1.iterations, r1.r_norm2)
+        os.environ.pop("MI355CG_TEAM_HALO_INLINE", None)
+    for r in (rt, rt2):
+        assert (r.iterations, r.r_norm2) == (r1.iterations, r1.r_norm2)
     assert np.array_equal(t.vector(0), s1._handle.solution())
     t.close()
 
