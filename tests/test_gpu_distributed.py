@@ -140,6 +140,8 @@ def test_bench_distributed_leg_runs_under_torchrun_with_rccl():
     assert j["n_gpus"] == 1 and j["steps"] == 60 and j["value"] > 0 and j["scaling"] == "weak"
     assert "native RCCL team" in j["config"]["parallelism"] and "note" not in j          # the native loop ran, not the fallback
     assert j["phases_ms"]["kernels_ms"] > 0 and j["phases_ms"]["wall_ms"] > 0
+    v = j["verify_against_one_gpu"]                                  # the line's own cross-check against a single context
+    assert v["ok"] is True and v["iterations"] == 30 and v["rel_diff"] <= 1e-12
 
 
 def test_slab_handles_refuse_the_whole_grid_entry_points():
