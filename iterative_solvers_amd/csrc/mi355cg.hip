@@ -405,7 +405,7 @@ void launch_check(mi355cg_ctx* c, const IterCfg& cfg, hipStream_t stream, const 
     hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, stream, a);
 }
 
-// The launch shapes of an iteration: REL_2NORM without diagnostics = two-step x update (7.5 words per unknown);
+// The launch shapes of an iteration: REL_2NORM without diagnostics = x folded every M-th iteration (M = 4: 7.25 words per unknown);
 // MSG, and REL_2NORM with the reference's per-iteration diagnostics = x and its norms every iteration (8 words, + u when read).
 IterCfg make_cfg(const mi355cg_params* prm) {
     IterCfg cfg{};
@@ -1173,7 +1173,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     HIPCK(hipEventRecord(c->ev_loop[1], c->stream));
     CgState fin = *c->summary_h;
     // Launches enqueued after the stop decision return in their prologue but still flipped c->cur on the
-    // host: the direction of the last REAL iteration is p[it % 2] (the solve starts with cur = 0).
+    // host: the direction of the last REAL iteration is p[it % M] (the solve starts with cur = 0).
     c->cur = fin.it % c->xsteps;
     if (cfg.x2) {                                   // folded x update: the steps after the last multiple of M are still pending
         launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, c->stream);

@@ -2,7 +2,8 @@
 """In-process sweep of the launch-geometry knobs (env vars read at mi355cg_create): item height, waves, rows in flight.
 Usage: python tools/tune.py N iters [f32] -- "K=V K=V" "K=V" ...      (each quoted group is one configuration; "" = defaults)
 Prints iterations/s and, per launch kind, the mean in-loop duration (HIP events) and the bandwidth its compulsory
-bytes correspond to (stencil 3 words; update 3 words on odd / 6 on even iterations = 4.5 on average)."""
+bytes correspond to (stencil 3 words; update 3 words on three iterations of four and 8 on the fourth = 4.25 on average;
+MI355CG_XSTEPS=2: 3 / 6 alternating = 4.5)."""
 import os
 import sys
 import time
