@@ -444,10 +444,20 @@ template <typename V> __device__ inline V buf_load(rsrc_t r, int voff, int soff)
     else if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
     else { static_assert(sizeof(V) == 4, "buf_load: 4, 8 or 16 bytes"); return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)); }
 }
+// HAZARD (measured on gfx950, ROCm 7.2; profiles/r02_tune_notes.md section 10): a VALU instruction that overwrites a data
+// register of a 128-bit buffer store in the very next slot is seen by the store -- the lanes read last (12..15 of every row of
+// 16) go to memory with the NEW value.  The ISA lists this hazard (VMEM store of more than 64 bits, then a VALU write of its
+// vdata: 1 wait state) and hipcc pads it for FLAT stores and for MUBUF stores WITHOUT a register soffset; with the soffset in
+// an SGPR (every store here: the row offset) it pads nothing.  The empty asm below keeps the data registers alive across two
+// wait states after the store, so nothing can be scheduled into that window that writes them.
 template <typename V> __device__ inline void buf_store(V v, rsrc_t r, int voff, int soff) {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-    if constexpr (sizeof(V) == 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, soff, 0);
+    if constexpr (sizeof(V) == 16) {
+        u4 d = __builtin_bit_cast(u4, v);
+        __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
+        asm volatile("s_nop 1" : "+v"(d));
+    }
     else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, voff, soff, 0);
     else { static_assert(sizeof(V) == 4, "buf_store: 4, 8 or 16 bytes"); __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0); }
 }

@@ -291,7 +291,9 @@ void build_plans(mi355cg_ctx* c) {
         const int n4 = region_rects(gp, 4, g.y_lo, g.y_hi, 0, strips_total(gp, 4), r4);
         c->whole32 = make_plan(std::vector<Rect>(r4, r4 + n4), kMaxRowsF32);
     }
-    c->depth = env_int("MI355CG_DEPTH", 2) == 3 ? 3 : 2;
+    // rows in flight per wave: 3 measured +1.5 % at N = 4096 and neutral elsewhere (profiles/r02_tune_notes.md section 9); the
+    // 12-word update of MI355CG_XSTEPS=8 would need 290 VGPRs at 3 (one wave per SIMD instead of two) and stays at 2
+    c->depth = env_int("MI355CG_DEPTH", 3) == 2 ? 2 : 3;
     c->use_graph = env_int("MI355CG_GRAPH", -1);
     c->nB_own = c->whole.grid;
 }
@@ -361,7 +363,7 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
     if (rec) a.rec = *rec;
     const dim3 grid(w.plan->grid), block(kBlock);
-    const bool d3 = c->depth == 3;
+    const bool d3 = c->depth == 3 && !(cfg.x2 && c->cur == 0 && c->xsteps == 8);
 #define MI355CG_UST(XM, HASU) do { if (d3) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 3, true>), grid, block, 0, w.stream, a); \
                                    else hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 2, true>), grid, block, 0, w.stream, a); } while (0)
     if (cfg.x2) {                    // iterations k = 0 mod M carry all M x steps (c->cur = k % M)

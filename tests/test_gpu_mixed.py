@@ -55,3 +55,40 @@ def test_config3_8192_mixed_full_solve():
     assert res.converged and res.refine_true_rel <= 1e-8
     og = OracleGrid(N, N)                                            # fp64 reference operator on the CPU
     assert np.linalg.norm(b - og.apply(x)) / np.linalg.norm(b) <= 1e-8
+
+
+FP32_SHAPES = [
+    {},                                                         # default: 64-row items of 256-column strips, 3 rows in flight
+    {"MI355CG_DEPTH": "2"},
+    {"MI355CG_ITEM_ROWS": "5"},
+    {"MI355CG_ITEM_ROWS": "1", "MI355CG_DEPTH": "2"},
+    {"MI355CG_XSTEPS": "2"},
+    {"MI355CG_XCD_CLASSES": "0"},
+    {"MI355CG_BLOCKS": "40", "MI355CG_ITEM_ROWS": "23"},
+]
+
+
+@pytest.mark.parametrize("N", [514, 2050])
+def test_fp32_launch_shapes_take_identical_steps(N, monkeypatch):
+    """The fp32 kernels in every launch shape: same iteration counts, same x, same residual, bit for bit (the inner products are
+    double-double sums, so the shape must not show).  N = 2050 has XCD-local item ranges and one item per wave: the shape in
+    which a 128-bit store followed by a write to its data registers first went wrong (see buf_store in csrc/cg_kernels.h)."""
+    import iterative_solvers_amd as isa
+    ref = None
+    for env in FP32_SHAPES:
+        for k in ("MI355CG_DEPTH", "MI355CG_ITEM_ROWS", "MI355CG_XSTEPS", "MI355CG_XCD_CLASSES", "MI355CG_BLOCKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+        sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+        x = sol.solve()
+        r = sol.last_results
+        got = (r.iterations, r.refine_outer, r.refine_true_rel, r.converged)
+        s._handle.close()
+        if ref is None:
+            ref = (got, x)
+            assert r.converged
+        else:
+            assert got == ref[0], (env, got, ref[0])
+            assert np.array_equal(x, ref[1]), env

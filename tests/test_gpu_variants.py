@@ -9,12 +9,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [
-    {},                                                     # default: ~32-row items dealt round-robin to 2 048 waves, 2 rows in flight
+    {},                                                     # default: one round of tall items over 2 048 waves, 3 rows in flight
     {"MI355CG_ITEM_ROWS": "7"},                             # odd item height, many rounds per wave
-    {"MI355CG_ITEM_ROWS": "1"},                             # every item fetches 3 rows and computes 1: the fetch cursor is always in the next item
+    {"MI355CG_ITEM_ROWS": "1"},                             # every item fetches 3 rows and computes 1: with 3 rows in flight the fetch cursor is a whole item ahead
     {"MI355CG_ITEM_ROWS": "1000000"},                       # one tall item per wave (round 1's shape)
-    {"MI355CG_DEPTH": "3"},                                 # 3 rows in flight
-    {"MI355CG_DEPTH": "3", "MI355CG_ITEM_ROWS": "1"},
+    {"MI355CG_DEPTH": "2"},                                 # 2 rows in flight (default 3)
+    {"MI355CG_DEPTH": "2", "MI355CG_ITEM_ROWS": "1"},
     {"MI355CG_BLOCKS": "37"},
     {"MI355CG_WAVES": "256", "MI355CG_ITEM_ROWS": "5"},
     {"MI355CG_XSTEPS": "8"},                                # x folded every 8th iteration (12-word launch, 247 VGPRs)
