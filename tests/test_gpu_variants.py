@@ -80,3 +80,21 @@ def test_two_step_x_update_is_flushed_for_odd_and_even_counts(stop_at):
     o = og.mf_solve(eps=1e-10, max_iterations=stop_at)
     assert o.iterations == stop_at
     np.testing.assert_allclose(x, o.x, rtol=1e-12, atol=1e-14)
+
+
+def test_random_launch_shapes_take_identical_steps():
+    """tools/shape_fuzz.py: 50 random combinations of the launch-geometry knobs, grid sizes, both precisions and both rules, a few
+    iterations each, against the default shape of the same problem -- x and r bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import shape_fuzz
+    saved = {k: os.environ.get(k) for k in shape_fuzz.KNOBS}
+    try:
+        assert shape_fuzz.fuzz(50, 20261004, verbose=False) == []
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
