@@ -176,10 +176,33 @@ long og_assemble_csr(const og_grid *g, int *row_map, int *entries, double *value
     return nnz;
 }
 
+/* NOT the reference: the same inner product evaluated as if in twice the working precision (Dot2 of Ogita, Rump & Oishi:
+ * error-free product and sum transformations, the rounding errors carried in a second double).  Switched on by the tests
+ * that separate "the reference's arithmetic" from "the reference's summation order": with exact inner products every other
+ * operation of the CG loop is elementwise and identical on both sides, so the GPU has to reproduce the oracle to the bit
+ * at any size, while against the serial sums below it can only agree to ~ U * 2^-53. */
+static int g_exact_dots = 0;
+void og_set_exact_dots(int on) { g_exact_dots = on; }
+static double og_dot2(const double *a, const double *b, long n)
+{
+    double s = 0.0, c = 0.0;
+    for (long i = 0; i < n; ++i) {
+        const double p = a[i] * b[i];
+        const double e = fma(a[i], b[i], -p);             /* a*b = p + e exactly */
+        const double t = s + p;
+        const double z = t - s;
+        const double q = (s - (t - z)) + (p - z);         /* s + p = t + q exactly */
+        s = t;
+        c += q + e;
+    }
+    return s + c;
+}
+
 /* std::inner_product(v1, v1+n, v2, 0.0) (matrix_free_system.cpp:364-366) and
  * MSGSolver::dot (msg_solver.cpp:215-229): serial ascending sum of products */
 double og_dot(const double *a, const double *b, long n)
 {
+    if (g_exact_dots) return og_dot2(a, b, n);
     double result = 0.0;
     for (long i = 0; i < n; ++i) result += a[i] * b[i];
     return result;

@@ -87,6 +87,7 @@ void og_msg_solve(const og_grid *g, const double *b, const double *true_solution
 
 /* helpers exposed for tests */
 double og_dot(const double *a, const double *b, long n);       /* serial ascending, init 0.0  */
+void og_set_exact_dots(int on);   /* tests only: inner products as if in twice the working precision (see cg_oracle.c) */
 double og_max_norm(const double *a, long n);
 
 #ifdef __cplusplus

@@ -81,6 +81,8 @@ def lib():
         L.og_msg_solve.restype = None
         L.og_dot.argtypes = [_DP, _DP, C.c_long]
         L.og_dot.restype = C.c_double
+        L.og_set_exact_dots.argtypes = [C.c_int]
+        L.og_set_exact_dots.restype = None
         L.og_max_norm.argtypes = [_DP, C.c_long]
         L.og_max_norm.restype = C.c_double
         _lib = L
@@ -252,3 +254,16 @@ def mf_solve_all_cores(n: int, b: np.ndarray, eps: float, max_iterations: int):
     x = np.empty(g.size)
     its = L.og_mf_solve_omp(C.byref(g), np.ascontiguousarray(b, dtype=np.float64), eps, max_iterations, x)
     return its, x, L.og_omp_threads()
+
+
+class exact_dots:
+    """with exact_dots(): ...  -- inner products of every oracle solve inside the block are evaluated as if in twice the working
+    precision (og_set_exact_dots).  Not the reference's arithmetic: the tool that tells its summation ORDER from everything else."""
+
+    def __enter__(self):
+        lib().og_set_exact_dots(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().og_set_exact_dots(0)
+        return False

@@ -364,6 +364,65 @@ def test_full_size_4096_apply_and_cg_properties(isa, oracle):
     assert np.abs(rg - (b - og.apply(xg))).max() <= 1e-9 * np.abs(b).max()
 
 
+@pytest.mark.parametrize("N,k", [(64, 10 ** 5), (258, 10 ** 5), (514, 10 ** 5), (1026, 400), (4096, 40)])
+def test_gpu_equals_the_oracle_with_exact_inner_products(isa, oracle, N, k):
+    """What separates the GPU from the reference is the ORDER in which the inner products are summed, and nothing else: give the
+    oracle inner products evaluated as if in twice the working precision (oracle.exact_dots: Dot2; every other operation of the
+    loop is elementwise and untouched) and the GPU reproduces it BIT FOR BIT -- x, the residual, every norm, the iteration count
+    and stop reason of full solves (N <= 514: to 1e-8 / 1e-9) and the first hundreds of iterations at the larger sizes."""
+    s = isa.GridSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    b = og.rhs()
+    sol = isa.MatrixFreeSolver(s, b, 1e-8, k)
+    xg = sol.solve()
+    with oracle.exact_dots():
+        ref = og.mf_solve(eps=1e-8, max_iterations=k)
+    assert (sol.getIterations(), bool(sol.last_results.converged)) == (ref.iterations, ref.converged)
+    assert (sol.last_results.r_norm2, sol.last_results.initial_r_norm2) == (ref.r_norm, ref.initial_r_norm)
+    assert np.array_equal(xg, ref.x)
+    m = isa.MSGSolver(s, b, 1e-9, k)
+    m.setPrecisionEps(1e-9); m.setResidualEps(1e-9); m.setExactErrorEps(1e-9)
+    cbs = []
+    m.setIterationCallback(lambda *a: cbs.append(a))
+    xm = m.solve(s.get_true_solution_vector())
+    with oracle.exact_dots():
+        rm = og.msg_solve(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=1e-9, max_iterations=k)
+    assert (m.getIterations(), int(m.getStopReason()), m.hasConverged()) == (rm.iterations, rm.stop_reason, rm.converged)
+    assert (m.getFinalResidualNorm(), m.getFinalPrecision(), m.getFinalErrorNorm()) == (rm.final_residual_norm, rm.final_precision, rm.final_error_norm)
+    assert [tuple(c) for c in cbs] == [tuple(c) for c in rm.callbacks]            # iteration numbers and all three norms of every callback
+    assert np.array_equal(xm, rm.x) and np.array_equal(s._handle.recursive_residual(), rm.r)
+
+
+def test_n8192_fp64_against_the_oracle(isa, oracle):
+    """The first size that lives in HBM rather than in the Infinity Cache (50 M unknowns, 400 MB per vector; configs 3-5 run at
+    such sizes): set-up vectors and the operator bit for bit; 10 CG iterations bit for bit against the oracle with exact inner
+    products, and within the reach of its serial sums (~U * 2^-53 per inner product, amplified by CG) against the oracle proper."""
+    import math
+    N = 8192
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    assert s.size() == og.size == 50315265
+    b = og.rhs()
+    assert np.array_equal(s.get_rhs(), b) and np.array_equal(s.get_true_solution_vector(), og.true_solution())
+    v = np.random.default_rng(12345).uniform(-1.0, 1.0, s.size())
+    assert np.array_equal(s.apply(v), og.apply(v))
+    del v
+    k = 10
+    sol = isa.MatrixFreeSolver(s, b, 1e-30, k)
+    xg = sol.solve()
+    with oracle.exact_dots():
+        ex = og.mf_solve(eps=1e-30, max_iterations=k)
+    assert sol.getIterations() == k == ex.iterations
+    assert (sol.last_results.r_norm2, sol.last_results.initial_r_norm2) == (ex.r_norm, ex.initial_r_norm)
+    assert np.array_equal(xg, ex.x)
+    exact = math.sqrt(math.fsum(np.square(b)))
+    assert abs(sol.last_results.initial_r_norm2 - exact) <= 2e-15 * exact
+    ref = og.mf_solve(eps=1e-30, max_iterations=k)                                   # the reference's own serial sums
+    assert sol.last_results.initial_r_norm2 == pytest.approx(ref.initial_r_norm, rel=1e-9)
+    assert sol.last_results.r_norm2 == pytest.approx(ref.r_norm, rel=2e-8)
+    assert np.abs(xg - ref.x).max() <= 1e-8 * np.abs(ref.x).max()
+
+
 def test_fixed_iteration_mode_ignores_convergence(isa):
     s = isa.MatrixFreeSystem(16, 16, 1.0, 2.0, 1.0, 2.0)
     sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-2, 40)

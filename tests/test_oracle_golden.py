@@ -105,3 +105,25 @@ def test_invalid_positions_return_minus_one():
     assert g.position(1, 1) == -1 and g.position(0, 5) == -1 and g.position(8, 5) == -1
     assert g.position(5, 1) == 0 and g.position(1, 5) == (8 // 2 - 1) * (8 // 2)
     assert g.is_boundary(4, 2) and g.is_boundary(2, 4) and not g.is_boundary(5, 4)
+
+
+def test_exact_dots_mode_of_the_oracle_is_what_it_says():
+    """oracle.exact_dots() (Dot2: inner products as if in twice the working precision) is the tool the GPU parity tests use to
+    separate the reference's summation ORDER from the rest of its arithmetic.  Here: it returns the exactly rounded value where
+    the serial sum does not, it changes nothing else, and it switches off again."""
+    import math
+    import numpy as np
+    from oracle import oracle as o
+    g = o.OracleGrid(130, 130)
+    b = g.rhs()
+    serial = o.dot(b, b)
+    with o.exact_dots():
+        exact = o.dot(b, b)
+        ex = g.mf_solve(eps=1e-8, max_iterations=10 ** 5)
+    from fractions import Fraction
+    true = sum(Fraction(float(v)) ** 2 for v in b)                       # exact rational arithmetic
+    assert exact == float(true) and serial != exact and abs(serial - exact) <= 1e-12 * exact
+    assert o.dot(b, b) == serial                                         # switched off again
+    ref = g.mf_solve(eps=1e-8, max_iterations=10 ** 5)
+    assert abs(ex.iterations - ref.iterations) <= 1 and np.abs(ex.x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
+    assert not np.array_equal(ex.x, ref.x)                               # the summation order does show in the last bits
