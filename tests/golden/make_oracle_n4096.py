@@ -4,6 +4,8 @@ the serial reference-faithful arithmetic takes 30-90 minutes per solve on one co
     python tests/golden/make_oracle_n4096.py mf        # MatrixFreeSolver rule, eps 1e-8 (no diagnostics)
     python tests/golden/make_oracle_n4096.py msg       # MSGSolver rules, precision+residual 1e-8
     python tests/golden/make_oracle_n4096.py mfdiag    # MatrixFreeSolver with the per-iteration diagnostics
+    python tests/golden/make_oracle_n4096.py mfexact   # MatrixFreeSolver rule with oracle.exact_dots() (Dot2 inner products)
+    python tests/golden/make_oracle_n4096.py msgexact  # MSGSolver rules with oracle.exact_dots()
     python tests/golden/make_oracle_n4096.py merge     # -> oracle_n4096.json
 
 The three legs are independent processes (run them side by side).  Vectors are kept as a strided sample
@@ -41,6 +43,20 @@ def leg(which):
         cbs = [c for c in m.callbacks if c[0] <= 10 or c[0] % 250 == 0 or c[0] >= m.iterations - 10]
         out = {"iterations": m.iterations, "converged": m.converged, "r_norm": m.r_norm,
                "initial_r_norm": m.initial_r_norm, "callbacks": cbs}
+    elif which == "mfexact":
+        from oracle import oracle as og
+        with og.exact_dots():
+            m = g.mf_solve(eps=1e-8, max_iterations=10**6)
+        out = {"iterations": m.iterations, "converged": m.converged, "r_norm": m.r_norm,
+               "initial_r_norm": m.initial_r_norm, "x": sample(m.x)}
+    elif which == "msgexact":
+        from oracle import oracle as og
+        with og.exact_dots():
+            r = g.msg_solve(eps_precision=1e-8, eps_residual=1e-8, eps_exact_error=-1.0, max_iterations=10**6)
+        out = {"iterations": r.iterations, "converged": r.converged, "stop_reason": r.stop_reason,
+               "final_residual_norm": r.final_residual_norm, "final_precision": r.final_precision,
+               "final_error_norm": r.final_error_norm, "r_norm2": r.r_norm2, "initial_r_norm2": r.initial_r_norm2,
+               "callbacks": r.callbacks, "x": sample(r.x), "r": sample(r.r)}
     elif which == "msg":
         r = g.msg_solve(eps_precision=1e-8, eps_residual=1e-8, eps_exact_error=-1.0, max_iterations=10**6)
         out = {"iterations": r.iterations, "converged": r.converged, "stop_reason": r.stop_reason,
@@ -57,7 +73,7 @@ def leg(which):
 if __name__ == "__main__":
     if sys.argv[1] == "merge":
         out = {}
-        for which in ("mf", "msg", "mfdiag"):
+        for which in ("mf", "msg", "mfdiag", "mfexact", "msgexact"):
             p = os.path.join(HERE, f"_n4096_{which}.part.json")
             if os.path.exists(p):
                 out[f"{which}_{N}"] = json.load(open(p))

@@ -589,6 +589,12 @@ def test_n4096_converged_against_the_oracle(isa):
     xs = np.array([float.fromhex(h) for h in mf["x"]["hex"]])
     assert np.abs(x[::mf["x"]["stride"]] - xs).max() <= 1e-9 * np.abs(xs).max()
     assert abs(np.abs(x).max() - mf["x"]["max_norm"]) <= 1e-9 * mf["x"]["max_norm"]
+    if "mfexact_4096" in ref:         # the same solve by the oracle with exact inner products (oracle.exact_dots): bit for bit
+        me = ref["mfexact_4096"]
+        assert (sol.getIterations(), sol.last_results.converged) == (me["iterations"], me["converged"])
+        assert (sol.last_results.r_norm2, sol.last_results.initial_r_norm2) == (me["r_norm"], me["initial_r_norm"])
+        assert [float(v).hex() for v in x[::me["x"]["stride"]]] == me["x"]["hex"]
+        assert np.abs(x).max() == me["x"]["max_norm"]
     if "mfdiag_4096" in ref:          # the reference's per-iteration report (2-norms, TRUE residual), sampled
         md = ref["mfdiag_4096"]
         got = {}
@@ -615,6 +621,14 @@ def test_n4096_converged_against_the_oracle(isa):
         assert np.abs(np.array([c[2] for c in cbs]) - np.array([c[2] for c in mr["callbacks"]])).max() / mf["initial_r_norm"] <= 1e-10
         xs = np.array([float.fromhex(h) for h in mr["x"]["hex"]])
         assert np.abs(xm[::mr["x"]["stride"]] - xs).max() <= 1e-9 * np.abs(xs).max()
+        if "msgexact_4096" in ref:    # MSG rules by the oracle with exact inner products: every callback and the result bit for bit
+            mx = ref["msgexact_4096"]
+            assert (m.getIterations(), int(m.getStopReason()), m.hasConverged()) == (mx["iterations"], mx["stop_reason"], mx["converged"])
+            assert (m.getFinalResidualNorm(), m.getFinalPrecision(), m.getFinalErrorNorm(), m.last_results.r_norm2) == \
+                   (mx["final_residual_norm"], mx["final_precision"], mx["final_error_norm"], mx["r_norm2"])
+            assert [list(c) for c in cbs] == [list(c) for c in mx["callbacks"]]
+            assert [float(v).hex() for v in xm[::mx["x"]["stride"]]] == mx["x"]["hex"]
+            assert [float(v).hex() for v in s._handle.recursive_residual()[::mx["r"]["stride"]]] == mx["r"]["hex"]
 
 
 def test_a_solve_does_not_depend_on_what_the_previous_one_left_behind(isa):
