@@ -228,3 +228,22 @@ def test_team_lifecycle_cycles_and_interleaved_handles():
             assert (r.iterations, r.r_norm2) == ref[:2]
         assert np.array_equal(t.vector(0), ref[2]) and np.array_equal(s._handle.solution(), ref[2])
         t.close(); s._handle.close()
+
+
+def test_random_decompositions_match_one_gpu():
+    """tools/team_fuzz.py: 60 random (grid, number of parts, rows / 2-D, rule, iteration count, launch knobs, interior+edge
+    launches, one thread per part) LOCAL teams against the single context: x, r and the norms bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import team_fuzz
+    saved = {k: os.environ.get(k) for k in team_fuzz.TEAM_KNOBS}
+    try:
+        bad, skipped = team_fuzz.fuzz(60, 20261004, verbose=False)
+        assert bad == [] and skipped < 30
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
