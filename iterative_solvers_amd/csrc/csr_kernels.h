@@ -27,7 +27,18 @@ __global__ __launch_bounds__(kBlock) void k_csr_xpay(const XpayArgs a) {
     if (d.done) return;
     const double beta = d.beta;
     const long long stride = (long long)gridDim.x * kBlock;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) a.p[i] = a.r[i] + beta * a.p[i];   // z = r + beta*z
+    // 16 bytes per lane (the vectors come from hipMalloc: 256-byte aligned); an odd last element goes to one thread
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const v2* __restrict__ R = reinterpret_cast<const v2*>(a.r);
+    v2* __restrict__ P = reinterpret_cast<v2*>(a.p);
+    const long long nv = a.n / 2;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) {
+        const v2 rv = R[i], pv = P[i];
+        v2 o;
+        o[0] = rv[0] + beta * pv[0]; o[1] = rv[1] + beta * pv[1];                                                          // z = r + beta*z
+        P[i] = o;
+    }
+    if ((a.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) a.p[a.n - 1] = a.r[a.n - 1] + beta * a.p[a.n - 1];
 }
 
 // ---- y = A x (CSR-stream): a block owns 256 consecutive rows, stages their products v_j * x[col_j] through LDS with
