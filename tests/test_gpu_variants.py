@@ -98,3 +98,21 @@ def test_random_launch_shapes_take_identical_steps():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_headline_throughput_has_not_regressed():
+    """Config 2 (N = 4096 fp64, REL_2NORM): 1 000 fixed iterations.  The slowest box seen this round ran 7 196 it/s, the build of
+    round 1 6 700; the floor only catches a real regression (a lost overlap, a spilled kernel), not box-to-box spread."""
+    import time
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd import _capi
+    s = isa.MatrixFreeSystem(4096, 4096, 1.0, 2.0, 1.0, 2.0)
+    p = isa.default_params(_capi.RULE_REL_2NORM)
+    p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = 1000, 1, 0, 0, 500
+    s._handle.solve(p)
+    t0 = time.perf_counter()
+    r = s._handle.solve(p)
+    dt = time.perf_counter() - t0
+    assert r.iterations == 1000
+    assert 1000 / dt >= 6300, f"{1000 / dt:.0f} it/s"
+    assert 1000 / r.loop_seconds >= 6300
