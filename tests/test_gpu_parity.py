@@ -423,6 +423,26 @@ def test_n8192_fp64_against_the_oracle(isa, oracle):
     assert np.abs(xg - ref.x).max() <= 1e-8 * np.abs(ref.x).max()
 
 
+def test_config4_grid_against_the_oracle_with_exact_inner_products(isa, oracle):
+    """N = 16384 (BASELINE config 4's grid, 201 M unknowns, 1.6 GB per vector) on one GPU: right-hand side and 4 CG iterations bit
+    for bit against the oracle with exact inner products.  test_gpu_team.py ties the 2 x 2 and slab teams of this size to the same
+    single-GPU bits."""
+    N = 16384
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    assert s.size() == og.size == 201293825
+    b = og.rhs()
+    assert np.array_equal(s.get_rhs(), b)
+    k = 4
+    sol = isa.MatrixFreeSolver(s, b, 1e-30, k)
+    xg = sol.solve()
+    with oracle.exact_dots():
+        ex = og.mf_solve(eps=1e-30, max_iterations=k)
+    assert sol.getIterations() == k == ex.iterations
+    assert (sol.last_results.r_norm2, sol.last_results.initial_r_norm2) == (ex.r_norm, ex.initial_r_norm)
+    assert np.array_equal(xg, ex.x)
+
+
 def test_fixed_iteration_mode_ignores_convergence(isa):
     s = isa.MatrixFreeSystem(16, 16, 1.0, 2.0, 1.0, 2.0)
     sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-2, 40)
