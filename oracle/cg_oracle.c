@@ -355,6 +355,93 @@ void og_msg_solve(const og_grid *g, const double *b, const double *true_solution
 }
 
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * NOT in the reference (it has no fp32 path): a CPU statement of the mixed-precision algorithm that BASELINE config 3 asks of
+ * the GPU library (csrc/mi355cg.hip solve_mixed / inner_cg_f32) -- fp32-storage CG inside fp64 iterative refinement -- so that
+ * the fp32 kernels can be checked value for value against an independent implementation, not only through the fp64 residual
+ * of the answer.  Arithmetic contract (stated in DESIGN.md section 3): vectors of the inner CG are float; the stencil, the
+ * direction and the updates are evaluated in float in the operation order of the fp64 path; inner products are exact sums of
+ * the double products of the float values, rounded once; alpha and beta are formed in double and rounded to float; the
+ * refinement (x += correction, r = b - A x, its norm) is fp64. */
+static void og_apply_f32(const og_grid *g, const float *x, float *y)
+{
+    const int sz = g->size;
+    const float A = (float)g->A, xk = (float)g->x_k, yk = (float)g->y_k;
+    OG_FOR_EACH_NODE(g, xi, yi) {
+        if (og_is_boundary(g, xi, yi)) continue;
+        int row = og_position(g, xi, yi);
+        if (!(row >= 0 && row < sz)) continue;
+        float v = A * x[row];
+        if (!is_left(g, xi - 1, yi)) { int col = og_position(g, xi - 1, yi); if (col >= 0 && col < sz) v = v + xk * x[col]; }
+        if (!is_right(g, xi + 1, yi)) { int col = og_position(g, xi + 1, yi); if (col >= 0 && col < sz) v = v + xk * x[col]; }
+        if (!is_top(g, xi, yi + 1)) { int col = og_position(g, xi, yi + 1); if (col >= 0 && col < sz) v = v + yk * x[col]; }
+        if (!is_bottom(g, xi, yi - 1)) { int col = og_position(g, xi, yi - 1); if (col >= 0 && col < sz) v = v + yk * x[col]; }
+        y[row] = v;
+    }
+}
+static double og_dot_f32_exact(const float *a, const float *b, long n)      /* products of floats are exact in double */
+{
+    double s = 0.0, c = 0.0;
+    for (long i = 0; i < n; ++i) {
+        const double p = (double)a[i] * (double)b[i];
+        const double t = s + p, z = t - s;
+        c += (s - (t - z)) + (p - z);
+        s = t;
+    }
+    return s + c;
+}
+/* inner CG in float on (x = 0, r = right-hand side); returns the iterations taken */
+static int og_inner_cg_f32(const og_grid *g, float *x, float *r, float *p, float *Ap, double eps, int max_iterations)
+{
+    const int n = g->size;
+    for (int i = 0; i < n; ++i) { x[i] = 0.0f; p[i] = 0.0f; }
+    double rr = og_dot_f32_exact(r, r, n), rr_prev = 0.0;
+    const double r0norm = sqrt(rr);
+    int it = 0;
+    for (;;) {
+        if (!(it < max_iterations && sqrt(rr) > eps * r0norm)) break;
+        const float beta = (float)(it == 0 ? 0.0 : rr / rr_prev);
+        for (int i = 0; i < n; ++i) p[i] = r[i] + beta * p[i];
+        og_apply_f32(g, p, Ap);
+        const double pAp = og_dot_f32_exact(Ap, p, n);
+        const float alpha = (float)(rr / pAp);
+        for (int i = 0; i < n; ++i) { x[i] = x[i] + alpha * p[i]; r[i] = r[i] - alpha * Ap[i]; }
+        rr_prev = rr;
+        rr = og_dot_f32_exact(r, r, n);
+        ++it;
+    }
+    return it;
+}
+void og_mixed_solve(const og_grid *g, const double *b, double eps, int max_iterations, double inner_eps, double *x,
+                    og_mixed_result *res)
+{
+    const int n = g->size;
+    float *xf = malloc(sizeof(float) * n), *rf = malloc(sizeof(float) * n), *pf = malloc(sizeof(float) * n), *Apf = malloc(sizeof(float) * n);
+    double *Ax = malloc(sizeof(double) * n), *r64 = malloc(sizeof(double) * n);
+    const int saved = g_exact_dots;
+    g_exact_dots = 1;                                              /* fp64 norms of the refinement: exact sums as well */
+    for (int i = 0; i < n; ++i) { x[i] = 0.0; r64[i] = b[i] - 0.0; rf[i] = (float)r64[i]; }
+    const double bnorm = sqrt(og_dot(r64, r64, n));
+    double rnorm = bnorm;
+    int total = 0, outer = 0, converged = bnorm == 0.0;
+    if (inner_eps <= 0) inner_eps = 1e-4;
+    while (!converged && total < max_iterations) {
+        const int its = og_inner_cg_f32(g, xf, rf, pf, Apf, inner_eps, max_iterations - total);
+        total += its; ++outer;
+        for (int i = 0; i < n; ++i) x[i] += (double)xf[i];
+        og_apply(g, x, Ax);
+        for (int i = 0; i < n; ++i) { r64[i] = b[i] - Ax[i]; rf[i] = (float)r64[i]; }
+        const double prev = rnorm;
+        rnorm = sqrt(og_dot(r64, r64, n));
+        converged = rnorm <= eps * bnorm;
+        if (its == 0) break;
+        if (!converged && rnorm > 0.5 * prev) break;               /* fp32 cannot improve this x any further */
+    }
+    g_exact_dots = saved;
+    if (res) { res->iterations = total; res->outer = outer; res->converged = converged; res->rnorm = rnorm; res->bnorm = bnorm; }
+    free(xf); free(rf); free(pf); free(Apf); free(Ax); free(r64);
+}
+
 /* ---- all-cores variant (timing baseline only) ----------------------------------------------------------------
  * Same per-element arithmetic as og_apply / og_mf_solve, rows distributed over OpenMP threads; the dot products use
  * an OpenMP reduction, so their summation order (hence the last bits) differs from the serial reference-faithful

@@ -87,6 +87,9 @@ void og_msg_solve(const og_grid *g, const double *b, const double *true_solution
 
 /* helpers exposed for tests */
 double og_dot(const double *a, const double *b, long n);       /* serial ascending, init 0.0  */
+typedef struct { int iterations, outer, converged; double rnorm, bnorm; } og_mixed_result;
+/* tests only: CPU statement of the library's mixed-precision algorithm (config 3; see cg_oracle.c) */
+void og_mixed_solve(const og_grid *g, const double *b, double eps, int max_iterations, double inner_eps, double *x, og_mixed_result *res);
 void og_set_exact_dots(int on);   /* tests only: inner products as if in twice the working precision (see cg_oracle.c) */
 double og_max_norm(const double *a, long n);
 

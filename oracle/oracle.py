@@ -33,6 +33,10 @@ class _MsgResult(C.Structure):
                 ("initial_r_norm2", C.c_double)]
 
 
+class _MixedResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("outer", C.c_int), ("converged", C.c_int), ("rnorm", C.c_double), ("bnorm", C.c_double)]
+
+
 class _MfResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("converged", C.c_int),
                 ("r_norm", C.c_double), ("initial_r_norm", C.c_double)]
@@ -81,6 +85,8 @@ def lib():
         L.og_msg_solve.restype = None
         L.og_dot.argtypes = [_DP, _DP, C.c_long]
         L.og_dot.restype = C.c_double
+        L.og_mixed_solve.argtypes = [GP, _DP, C.c_double, C.c_int, C.c_double, _DP, C.POINTER(_MixedResult)]
+        L.og_mixed_solve.restype = None
         L.og_set_exact_dots.argtypes = [C.c_int]
         L.og_set_exact_dots.restype = None
         L.og_max_norm.argtypes = [_DP, C.c_long]
@@ -186,6 +192,15 @@ class OracleGrid:
         lib().og_mf_solve(C.byref(self._g), b, u.ctypes.data, eps, max_iterations,
                           1 if diagnostics else 0, cb, None, x, C.byref(res))
         return MfResult(x, res.iterations, bool(res.converged), res.r_norm, res.initial_r_norm, cbs)
+
+    def mixed_solve(self, b=None, eps=1e-8, max_iterations=10 ** 6, inner_eps=0.0):
+        """NOT the reference (it has no fp32 path): CPU statement of the library's mixed-precision algorithm of BASELINE config 3
+        (og_mixed_solve).  Returns (x, iterations, outer refinement steps, converged, ||b - A x||_2 / ||b||_2)."""
+        b = self.rhs() if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        x = np.empty(self.size)
+        res = _MixedResult()
+        lib().og_mixed_solve(C.byref(self._g), b, eps, max_iterations, inner_eps, x, C.byref(res))
+        return x, res.iterations, res.outer, bool(res.converged), (res.rnorm / res.bnorm if res.bnorm > 0 else 0.0)
 
     def msg_solve(self, b=None, true_solution="default", eps_precision=1e-6, eps_residual=1e-6,
                   eps_exact_error=-1.0, max_iterations=10000) -> MsgResult:

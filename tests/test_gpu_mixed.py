@@ -92,3 +92,23 @@ def test_fp32_launch_shapes_take_identical_steps(N, monkeypatch):
         else:
             assert got == ref[0], (env, got, ref[0])
             assert np.array_equal(x, ref[1]), env
+
+
+@pytest.mark.parametrize("N", [34, 66, 258, 514])
+def test_mixed_solve_equals_the_cpu_statement_of_the_algorithm(N):
+    """The fp32 kernels value for value: oracle.mixed_solve is an independent CPU implementation of the SAME algorithm (float
+    vectors and float arithmetic in the fp64 path's operation order, exact inner products rounded once, alpha / beta formed in
+    double and rounded to float, fp64 refinement; oracle/cg_oracle.c og_mixed_solve -- the reference itself has no fp32 path).
+    Same inner iteration total, same number of refinement steps, and the same x to the last bit."""
+    import iterative_solvers_amd as isa
+    from oracle.oracle import OracleGrid
+    og = OracleGrid(N, N)
+    b = og.rhs()
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    sol = isa.MatrixFreeSolver(s, b, 1e-8, 10 ** 6)
+    x = sol.solve()
+    r = sol.last_results
+    xo, its, outer, conv, rel = og.mixed_solve(b, eps=1e-8)
+    assert (r.iterations, r.refine_outer, bool(r.converged)) == (its, outer, conv)
+    assert np.array_equal(x, xo)
+    assert r.refine_true_rel == pytest.approx(rel, rel=1e-10)

@@ -127,3 +127,18 @@ def test_exact_dots_mode_of_the_oracle_is_what_it_says():
     ref = g.mf_solve(eps=1e-8, max_iterations=10 ** 5)
     assert abs(ex.iterations - ref.iterations) <= 1 and np.abs(ex.x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
     assert not np.array_equal(ex.x, ref.x)                               # the summation order does show in the last bits
+
+
+def test_mixed_precision_statement_of_the_oracle_converges_in_fp64_terms():
+    """oracle.mixed_solve (CPU statement of the library's config-3 algorithm; not the reference, which has no fp32 path): its
+    answer has to satisfy the fp64 system to 1e-8 and sit next to the fp64 CG solution."""
+    import numpy as np
+    from oracle import oracle as o
+    g = o.OracleGrid(130, 130)
+    b = g.rhs()
+    x, its, outer, conv, rel = g.mixed_solve(b, eps=1e-8)
+    assert conv and outer >= 2 and its > 100
+    true_rel = np.linalg.norm(b - g.apply(x)) / np.linalg.norm(b)
+    assert true_rel <= 1e-8 and abs(true_rel - rel) <= 1e-12
+    ref = g.mf_solve(eps=1e-10, max_iterations=10 ** 5)
+    assert np.abs(x - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
