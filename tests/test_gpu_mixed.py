@@ -112,3 +112,23 @@ def test_mixed_solve_equals_the_cpu_statement_of_the_algorithm(N):
     assert (r.iterations, r.refine_outer, bool(r.converged)) == (its, outer, conv)
     assert np.array_equal(x, xo)
     assert r.refine_true_rel == pytest.approx(rel, rel=1e-10)
+
+
+def test_mixed_solve_n2050_against_the_cpu_fixture():
+    """The same comparison at N = 2050 (XCD-local item ranges in the fp32 launch plan; 7 292 inner iterations), against the
+    15-minute CPU run kept in tests/golden/oracle_mixed_n2050.json (tests/golden/make_oracle_mixed.py)."""
+    import json
+    import os
+    import iterative_solvers_amd as isa
+    path = os.path.join(os.path.dirname(__file__), "golden", "oracle_mixed_n2050.json")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    ref = json.load(open(path))
+    N = ref["n"]
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    sol = isa.MatrixFreeSolver(s, s.get_rhs(), 1e-8, 10 ** 6)
+    x = sol.solve()
+    r = sol.last_results
+    assert (r.iterations, r.refine_outer, bool(r.converged)) == (ref["iterations"], ref["outer"], ref["converged"])
+    assert [float(v).hex() for v in x[::ref["x"]["stride"]]] == ref["x"]["hex"]
+    assert r.refine_true_rel == pytest.approx(ref["true_rel"], rel=1e-9)
