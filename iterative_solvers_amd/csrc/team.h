@@ -13,15 +13,18 @@
 //          The records: ncclAllGather issued on the COMPUTE stream, between producer and consumer launch (nothing else
 //          could run there: both launches of an iteration need all records).  The halo: one ncclSend/ncclRecv group per
 //          iteration on a SECOND stream and a second communicator, ordered with the compute stream by two events, so it
-//          overlaps the interior launches.  The host never blocks inside an iteration.
-//   LOCAL  one process drives all parts, on one or several GPUs: records are written straight into every part's gathered
-//          buffer, halo segments are device-to-device copies.  This is what a single-process host (the reference's
-//          DirichletSolver is one) uses, and what lets one GPU rehearse an 8-part run bit for bit.
-// Per iteration and part:   compute stream                              comm stream
-//     stencil (interior items)                                     |  [halo of r from the previous update still in flight]
-//     wait halo ; stencil (edge rows / strips) ; record A  ------->|  all-gather A
-//     wait A ; update (edge) ; pack columns ---------------------->|  halo exchange of r ; unpack columns
-//     update (interior) ; record B  ------------------------------>|  all-gather B
+//          travels while the update records are all-gathered.  The host never blocks inside an iteration.
+//   LOCAL  one process drives all parts, on one or several GPUs (one host thread per part when they are on different GPUs):
+//          records are written straight into every part's gathered buffer, halo segments are device-to-device copies.
+//          This is what a single-process host (the reference's DirichletSolver is one) uses, and what lets one GPU rehearse
+//          an 8-part run bit for bit.
+// Per iteration and part (default: ONE launch per phase; MI355CG_TEAM_SPLIT=1 cuts each phase into interior + edge launches
+// so that the halo travels beside the interior items instead):
+//     compute stream                                                       comm stream
+//     wait halo ; stencil -> record A (last block of the launch)
+//     all-gather A
+//     update -> record B ; pack columns ---------------------------------> halo exchange of r ; unpack columns
+//     all-gather B                                                        |
 // Sums travel as double-double pairs and are reduced in part order by every consumer, so every decomposition takes
 // bit-identical steps (tests/test_gpu_team.py).
 #include <dlfcn.h>
