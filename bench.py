@@ -6,21 +6,32 @@ config 2: N x N = 4096 x 4096 intervals on the L-shaped domain, fp64, U = 12 574
 RHS (the reference's f and Dirichlet data), x0 = 0, convergence tests disabled so that exactly K iterations are timed.
 
   python bench.py --gpus 1 --steps 2000 --warmup 200
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N ...                               (no launcher needed: rank processes are started from here)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form: same result)
       weak scaling (default): every rank owns a config-2-sized part, the global grid grows with N
       --scaling strong --grid 32768: BASELINE config 5's fixed grid cut into N parts
       --decomp rows | 2d: row slabs, or (N/2) x 2 blocks (config 4's "2 x 2" at N = 4)
 
+N > 1 (and MI355CG_BENCH_DIST=1 at N = 1): the measurement is a sequence of LEGS, each a fresh set of N rank processes (one per
+GPU) started by a coordinator that never touches a GPU itself: the order-safe RCCL schedule first, then the mailbox + push
+transport, then sub-records (two-stream RCCL halo, config 5 strong, config 4's 2 x 2 at N = 4, one process driving N devices).
+A leg that stalls is killed at its own time limit and noted; the legs that finished are never lost.  `value` = the best leg of
+the requested configuration that passed its cross-check against one GPU; every leg is in `legs`.
+
 Prints ONE JSON line (rank 0).  `value` = CG iterations/s of the whole job (weak scaling: in units of config-2-sized
-parts advanced per second), timed on the host around K iterations between device synchronisations; `hbm_gbps` = bytes the
-iteration really moves (58 B per unknown for the REL_2NORM loop) per second; the per-kernel roofline comes from HIP events.
+parts advanced per second), the MEDIAN of R timed solves of exactly K iterations each (host clock between device
+synchronisations, max over ranks); `hbm_gbps` = bytes the iteration really moves (58 B per unknown for the REL_2NORM loop) per
+second; the per-kernel roofline comes from HIP events.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import signal
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +50,25 @@ WORDS = {"rel2": {"stencil": 3, "update": (3 * (_M - 1) + (4 + _M)) / _M}, "msg"
 
 def unknowns(n: int) -> int:
     return (n // 2 - 1) * (3 * n // 2 - 1)
+
+
+def weak_scaling_n(n1: int, world: int) -> int:
+    """Grid size whose unknown count is ~world x that of n1 (even).  (= iterative_solvers_amd.distributed.weak_scaling_n, repeated
+    here because the coordinator must not import anything that could touch a GPU.)"""
+    return max(int(round(n1 * (world ** 0.5) / 2.0)) * 2, 6)
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def repeats(args, ms_per_step_guess: float) -> int:
+    """R timed solves of K iterations each: 11 unless that would take more than ~3 s of device time."""
+    if args.repeats > 0:
+        return args.repeats
+    per = max(1e-6, args.steps * ms_per_step_guess * 1e-3)
+    return max(1, min(11, int(3.0 / per)))
 
 
 def cpu_baseline(n: int, iters: int):
@@ -80,176 +110,305 @@ def read_traffic():
         return None
 
 
-def bench_team(args, rule):
-    """N > 1: one process per GPU, the native RCCL team (csrc/team.h)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1: legs.  The coordinator (this process, or every torchrun worker) only starts and watches child processes.
+# ---------------------------------------------------------------------------------------------------------------------
+TRANSPORTS = {
+    # name -> (environment of csrc/team.h's transport selection, what it is)
+    "rccl-inline": ({"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "inline", "MI355CG_TEAM_IPC": "0"},
+                    "records: ncclAllGather, halo: one ncclSend/ncclRecv group, both on the compute stream of ONE communicator (order-safe)"),
+    "mailbox+push": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "auto"},
+                     "records: stored by the producer launch's last block straight into every rank's IPC-mapped mailbox, polled by the consumer launch; "
+                     "halo: pushed into the neighbours' ghost cells by one small launch + a stream-ordered flag (RCCL only bootstraps)"),
+    "rccl-stream": ({"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "stream", "MI355CG_TEAM_IPC": "0"},
+                    "records: ncclAllGather on the compute stream, halo: ncclSend/ncclRecv on a second stream + second communicator"),
+    "mailbox+rccl-halo": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "inline"},
+                          "records through the mailboxes, halo as one RCCL group on the compute stream"),
+}
+
+
+def plan_legs(args):
+    """The legs of one invocation, in the order they run.  `headline` legs measure the requested configuration."""
+    N = args.gpus
+    base = {"scaling": args.scaling, "decomp": args.decomp, "grid": args.n, "driver": "ranks"}
+    legs = [dict(base, name="rccl-inline", transport="rccl-inline", headline=True),
+            dict(base, name="mailbox+push", transport="mailbox+push", headline=True)]
+    if args.legs == "all":
+        legs.append(dict(base, name="rccl-stream", transport="rccl-stream", headline=False))
+        if not (args.scaling == "strong" and args.n == 32768):
+            legs.append(dict(base, name="config5-strong-32768", transport="mailbox+push", headline=False, scaling="strong", grid=32768, decomp="rows", verify=0))
+        if N == 4 and not (args.decomp == "2d" and args.scaling == "strong" and args.n == 16384):
+            legs.append(dict(base, name="config4-2x2-16384", transport="mailbox+push", headline=False, scaling="strong", grid=16384, decomp="2d"))
+        if N > 1:          # last: in the torchrun form only rank 0's coordinator runs it, while the others are already done
+            legs.append(dict(base, name="local-one-process", transport="local", headline=False, driver="local"))
+    elif args.legs != "default":
+        want = args.legs.split(",")
+        legs = [l for l in legs if l["name"] in want] + [dict(base, name=w, transport=w, headline=True) for w in want if w in TRANSPORTS and w not in ("rccl-inline", "mailbox+push")]
+    return legs
+
+
+def run_leg_child(spec, args):
+    """One rank of one leg (a fresh process: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment)."""
+    import datetime
     import torch
     import torch.distributed as dist
     import iterative_solvers_amd as isa
     from iterative_solvers_amd import _capi
     from iterative_solvers_amd import distributed as D
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if "RANK" not in os.environ:                            # started without a launcher: one rank, still through RCCL
-        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
-        os.environ.setdefault("MASTER_PORT", "29531")
+    world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+    local = spec["driver"] == "local"
+    nparts = args.gpus if local else world
     torch.cuda.set_device(local_rank)
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    strong = args.scaling == "strong"
-    n = args.n if strong else D.weak_scaling_n(args.n, world)
-    U1, U = unknowns(args.n), unknowns(n)
-    decomp = _capi.DECOMP_2D if args.decomp == "2d" else _capi.DECOMP_ROWS
-    boxes = D.decompose(n, world, decomp)
-
-    path, note = "native RCCL team (csrc/team.h: ncclAllGather of 16-double records + neighbour ncclSend/ncclRecv on a second stream)", None
-    team = cg = None
-    try:
+    if not local:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))       # control plane only: the id, barriers, max over ranks
+    rule = _capi.RULE_REL_2NORM if args.rule == "rel2" else _capi.RULE_MSG_MAXNORM
+    strong = spec["scaling"] == "strong"
+    n = spec["grid"] if strong else weak_scaling_n(spec["grid"], nparts)
+    U1, U = unknowns(spec["grid"]), unknowns(n)                      # weak: a part is as large as the --grid problem (config 2 by default)
+    decomp = _capi.DECOMP_2D if spec["decomp"] == "2d" else _capi.DECOMP_ROWS
+    boxes = D.decompose(n, nparts, decomp)
+    ndev = torch.cuda.device_count()
+    if local:
+        team = D.Team.local(n, nparts, decomp, devices=list(range(min(ndev, nparts))))
+    else:
         team = D.Team.rccl(n, decomp, device=local_rank)
-    except Exception as e:                                  # keep the scaling run alive: the torch.distributed driver of round 1
-        note = f"native team unavailable ({repr(e)[:160]}); fell back to the torch.distributed driver over row slabs"
-        path = "torch.distributed driver (iterative_solvers_amd/distributed.py DistributedCG, halo=p2p)"
-        y_lo, y_hi = D.slab_rows(n, world, rank)
-        cg = D.DistributedCG(D.SlabEngine(n, y_lo, y_hi, device=local_rank), halo="p2p")
+    desc = team.describe()
+    if not local and desc["rccl_nranks"] != args.gpus:
+        raise RuntimeError(f"RCCL reports {desc['rccl_nranks']} ranks, --gpus asked for {args.gpus}")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if not local:
+            dist.barrier()
 
     def run(iters):
         p = isa.default_params(rule)
         p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = iters, 1, 0, 0, 500
-        return team.solve(p) if team else cg.solve(p)
+        return team.solve(p)
 
     run(args.warmup)
-    torch.cuda.synchronize(); dist.barrier()
-    t0 = time.perf_counter()
-    res = run(args.steps)
-    torch.cuda.synchronize(); dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=torch.device("cuda", local_rank))
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    assert res.iterations == args.steps
+    times = []
+    for _ in range(repeats(args, 0.14 * max(1.0, U / nparts / 12.6e6))):
+        barrier()
+        t0 = time.perf_counter()
+        res = run(args.steps)
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if not local:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        times.append(float(dt.item()))
+        assert res.iterations == args.steps
+    dt = median(times)
     its = args.steps / dt
-    phases = None
-    if team:
-        team.set_profiling(True)
-        run(min(args.steps, 200))
-        team.set_profiling(False)
-        phases = team.phase_times()
-        phases["driver_and_wait_ms"] = max(0.0, phases["wall_ms"] - phases["kernels_ms"])
-        phases["note"] = "rank 0, per iteration: device time of its kernels; device time of the collectives + halo messages on the comm stream (they overlap the kernels); wall"
+    team.set_profiling(True)
+    run(min(args.steps, 200))
+    team.set_profiling(False)
+    phases = team.phase_times()
+    phases["driver_and_wait_ms"] = max(0.0, phases["wall_ms"] - phases["kernels_ms"])
     # Cross-check of the distributed loop (untimed): V iterations on the team against the SAME global problem solved by ONE context
     # on rank 0's GPU.  The team's reductions are summed part by part in a fixed order, so the residual norm has to agree to
     # rounding of the last bit or two; a halo row that arrived late or in the wrong place shows up in the leading digits.
     verify = None
-    if (world > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1") and args.verify > 0:
-        if U <= args.verify_max_unknowns:
-            rv = run(args.verify)
-            torch.cuda.synchronize()
-            if rank == 0:
-                one = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=local_rank)
-                p = isa.default_params(rule)
-                p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = args.verify, 1, 0, 0, 500
-                r1 = one._handle.solve(p)
-                one._handle.close()
-                rel = abs(rv.r_norm2 - r1.r_norm2) / max(abs(r1.r_norm2), 1e-300)
-                verify = {"iterations": args.verify, "team_r_norm2": rv.r_norm2, "single_gpu_r_norm2": r1.r_norm2,
-                          "rel_diff": rel, "ok": bool(rel <= 1e-12 and rv.iterations == r1.iterations)}
-            dist.barrier()
-        else:
-            verify = {"skipped": f"{U} unknowns > --verify-max-unknowns {args.verify_max_unknowns}"}
+    nverify = spec.get("verify", args.verify)
+    if nverify > 0 and U <= args.verify_max_unknowns:
+        rv = run(nverify)
+        torch.cuda.synchronize()
+        if rank == 0:
+            one = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=local_rank)
+            p = isa.default_params(rule)
+            p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = nverify, 1, 0, 0, 500
+            r1 = one._handle.solve(p)
+            one._handle.close()
+            rel = abs(rv.r_norm2 - r1.r_norm2) / max(abs(r1.r_norm2), 1e-300)
+            verify = {"iterations": nverify, "team_r_norm2": rv.r_norm2, "single_gpu_r_norm2": r1.r_norm2,
+                      "rel_diff": rel, "bit_identical": bool(rv.r_norm2 == r1.r_norm2), "ok": bool(rel <= 1e-12 and rv.iterations == r1.iterations)}
+        barrier()
+    elif nverify > 0:
+        verify = {"skipped": f"{U} unknowns > --verify-max-unknowns {args.verify_max_unknowns}"}
     bytes_it = 8.0 * sum(WORDS[args.rule].values())
     units = 1.0 if strong else U / U1
-    moved = bytes_it * U * its / 1e9 / world
+    moved = bytes_it * U * its / 1e9 / nparts
     out = {
-        "metric": "cg_iters_per_sec", "value": round(its * units, 2), "unit": "iters/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5),
-        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"{n}x{n} L-shaped Dirichlet Poisson fp64 cut into {world} parts, matrix-free CG, fixed {args.steps} iterations"
-                                if strong else
-                                f"{n}x{n} L-shaped Dirichlet Poisson fp64 over {world} parts of ~{U1} unknowns (config-2 size per GPU), matrix-free CG, fixed {args.steps} iterations"),
-                   "n": n, "unknowns": U, "unknowns_per_gpu": U / world, "rule": args.rule,
-                   "value_is": "global CG iterations/s" if strong else "global CG iterations/s x (unknowns / config-2 unknowns) = config-2-sized part iterations/s",
-                   "decomposition": {"kind": "2d" if decomp else "rows", "parts": boxes},
-                   "parallelism": f"{'(N/2) x 2 blocks' if decomp else 'row slabs'} x{world}, one process per GPU, {path}"},
-        "global_iters_per_sec": round(its, 2),
-        "hbm_gbps": round(bytes_it * U * its / 1e9, 1),
-        "hbm_gbps_is": f"bytes really moved, summed over GPUs: {bytes_it:.0f} B per unknown per iteration",
-        "algorithmic_equivalent_gbps_88B": round(SURVEY_BYTES_PER_UNKNOWN * U * its / 1e9, 1),
-        "phases_ms": phases,
-        "verify_against_one_gpu": verify,
-        # whole-iteration roofline per GPU (kernels + collectives + driver); the per-kernel figures are in the 1-GPU bench line
-        "roofline": {"bound": "hbm", "achieved": round(moved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(moved / HBM_PEAK_GBPS, 4),
-                     "traffic": None, "scope": "bytes one GPU has to move per iteration / wall time per iteration, collectives included"},
+        "leg": spec["name"], "value": round(its * units, 2), "n_gpus": nparts, "global_iters_per_sec": round(its, 2),
+        "ms_per_step": round(1e3 * dt / args.steps, 5), "repeats": len(times),
+        "ms_per_step_min_max": [round(1e3 * min(times) / args.steps, 5), round(1e3 * max(times) / args.steps, 5)],
+        "scaling": "strong" if strong else "weak", "n": n, "unknowns": U, "unknowns_per_gpu": U / nparts,
+        "decomposition": {"kind": spec["decomp"], "parts": boxes},
+        "transport": desc, "processes": 1 if local else world, "devices_used": min(ndev, nparts) if local else world,
+        "hbm_gbps": round(bytes_it * U * its / 1e9, 1), "per_gpu_gbps": round(moved, 1), "per_gpu_frac_of_8000": round(moved / HBM_PEAK_GBPS, 4),
+        "phases_ms": phases, "verify_against_one_gpu": verify,
     }
-    if note:
-        out["note"] = note
-    dist.barrier()
-    if team:
-        team.close()
-    if "TORCHELASTIC_RUN_ID" not in os.environ and world == 1:
-        dist.destroy_process_group()                          # started without a launcher: leave nothing behind
+    team.close()
+    if not local:
+        dist.barrier()
+        dist.destroy_process_group()
     return out
 
 
-def main():
-    # ONE JSON line on stdout: libraries chat there too (RCCL prints a version banner when its first communicator comes up),
-    # so everything else this process writes to fd 1 goes to stderr until the line is printed.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+def child_main(args):
+    spec = json.loads(args.child_leg)
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        out = run_leg_child(spec, args)
+    except BaseException as e:                                       # noqa: BLE001 -- the coordinator wants the reason, whatever it was
+        out = {"leg": spec["name"], "error": f"rank {rank}: {type(e).__name__}: {str(e)[:300]}"}
+        with open(args.child_out + f".r{rank}", "w") as f:
+            json.dump(out, f)
+        raise
+    if rank == 0:
+        with open(args.child_out + ".r0", "w") as f:
+            json.dump(out, f)
 
-    def emit(obj):
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(obj), flush=True)
 
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid intervals per side (per GPU for weak scaling)")
-    ap.add_argument("--rule", choices=["rel2", "msg"], default="rel2")
-    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
-                    help="f32 = BASELINE config 3: the fp32-storage inner CG of the mixed-precision path (use --grid 8192)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak (part size fixed) or strong (--grid fixed)")
-    ap.add_argument("--decomp", choices=["rows", "2d"], default="rows", help="N > 1: row slabs or (N/2) x 2 blocks")
-    ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations for cpu_baseline (0 = skip)")
-    ap.add_argument("--no-roofline-pass", action="store_true")
-    ap.add_argument("--verify", type=int, default=30, help="N > 1: iterations of the untimed cross-check against one GPU (0 = skip)")
-    ap.add_argument("--verify-max-unknowns", type=float, default=2.6e8, help="skip that cross-check above this size (host set-up time)")
-    ap.add_argument("--watchdog", type=float, default=1500.0, help="seconds after which a stuck run reports an error line and exits")
-    args = ap.parse_args()
+def leg_command(args, spec, out_path):
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--grid", str(args.n), "--rule", args.rule, "--verify", str(args.verify), "--verify-max-unknowns", str(args.verify_max_unknowns),
+           "--repeats", str(args.repeats), "--child-leg", json.dumps(spec), "--child-out", out_path]
+    return cmd
 
-    # A collective that never completes must not hang the caller for ever: report and leave.
-    import threading
-    def _expired():
-        if int(os.environ.get("RANK", "0")) == 0:
-            emit({"metric": "cg_iters_per_sec", "value": None, "unit": "iters/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
-                  "error": f"no result after {args.watchdog:.0f} s (watchdog): the run was stuck, most likely in a collective"})
-        os._exit(3)
-    wd = threading.Timer(args.watchdog, _expired)
-    wd.daemon = True
-    wd.start()
 
+def leg_env(base_env, spec, rank, world, local_rank, port):
+    env = dict(base_env)
+    for k in ("MI355CG_TEAM_RECORDS", "MI355CG_TEAM_HALO", "MI355CG_TEAM_IPC", "MI355CG_TEAM_WAIT", "MI355CG_TEAM_SPLIT", "MI355CG_TEAM_HALO_INLINE"):
+        env.pop(k, None)
+    if spec["transport"] in TRANSPORTS:
+        env.update(TRANSPORTS[spec["transport"]][0])
+    env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(local_rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                "MI355CG_BENCH_CHILD": "1", "GLOO_SOCKET_IFNAME": env.get("GLOO_SOCKET_IFNAME", "lo"), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    env.setdefault("MI355CG_TEAM_TIMEOUT_MS", "20000")
+    for k in list(env):
+        if k.startswith("TORCHELASTIC") or k in ("GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+            env.pop(k)
+    return env
+
+
+def coordinate(args):
+    """Start the rank processes of every leg, watch them, collect rank 0's record.  Touches no GPU (imports no torch)."""
+    launched = int(os.environ.get("WORLD_SIZE", "1")) > 1          # torchrun (the driver's N > 1 form): this process is ONE rank's coordinator
+    world = args.gpus
+    if launched and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: the launcher started {os.environ['WORLD_SIZE']} ranks but --gpus is {args.gpus}")
+    my_ranks = [int(os.environ["RANK"])] if launched else list(range(world))
+    local_of = {r: (int(os.environ["LOCAL_RANK"]) if launched else r) for r in my_ranks}
+    lead = 0 in my_ranks
+    base_port = int(os.environ.get("MASTER_PORT", "29531")) + 101   # the launcher's own store keeps MASTER_PORT
+    legs = plan_legs(args)
+    results, notes = {}, []
+    t_start = time.time()
+    tmpdir = tempfile.mkdtemp(prefix="mi355cg_bench_")
+    for li, spec in enumerate(legs):
+        if time.time() - t_start > args.budget and results:
+            notes.append(f"leg {spec['name']} not started: {args.budget:.0f} s budget used up")
+            continue
+        local = spec["driver"] == "local"
+        if local and not lead:
+            continue
+        out_path = os.path.join(tmpdir, f"leg{li}")
+        ranks = [0] if local else my_ranks
+        procs = []
+        for r in ranks:
+            env = leg_env(os.environ, spec, 0 if local else r, 1 if local else world, local_of.get(r, 0), base_port + li)
+            log = open(os.path.join(tmpdir, f"leg{li}.r{r}.log"), "w")
+            procs.append((r, subprocess.Popen(leg_command(args, spec, out_path), env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True), log))
+        deadline = time.time() + args.leg_timeout
+        alive = list(procs)
+        failed = False
+        while alive and time.time() < deadline:
+            alive = [p for p in alive if p[1].poll() is None]
+            if any(p[1].returncode not in (None, 0) for p in procs):
+                failed = True
+                deadline = min(deadline, time.time() + 20.0)             # a rank died: the others are waiting for it in vain
+            time.sleep(0.05)
+        stalled = bool(alive)
+        for r, p, log in alive:                                           # exactly the process groups started above
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        for r, p, log in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+            log.close()
+        rec = None
+        for r in ranks:
+            f = f"{out_path}.r{r}"
+            if os.path.exists(f):
+                with open(f) as fh:
+                    got = json.load(fh)
+                if r == 0 or "error" in got:
+                    rec = got if rec is None or "error" in got else rec
+        if lead:
+            if rec is None:
+                tail = ""
+                try:
+                    with open(os.path.join(tmpdir, f"leg{li}.r0.log")) as fh:
+                        tail = fh.read()[-400:]
+                except OSError:
+                    pass
+                rec = {"leg": spec["name"], "error": ("stalled: killed after %.0f s" % args.leg_timeout) if stalled and not failed else f"no record (rank exit codes {[p[1].returncode for p in procs]}): {tail}"}
+            elif stalled and "error" not in rec:
+                rec["note"] = "some ranks had to be killed after the record was written"
+            rec["what"] = TRANSPORTS.get(spec["transport"], (None, "one process drives all parts (LOCAL transport: peer access, one host thread per device)"))[1]
+            rec["headline_candidate"] = bool(spec["headline"])
+            results[spec["name"]] = rec
+    if not lead:
+        return None
+    return legs, results, notes
+
+
+def compose(args, legs, results, notes):
+    cands = [results[l["name"]] for l in legs if l["headline"] and l["name"] in results and "error" not in results[l["name"]]]
+    verified = [r for r in cands if not r.get("verify_against_one_gpu") or r["verify_against_one_gpu"].get("ok", True)]
+    best = max(verified or cands, key=lambda r: r["value"]) if (verified or cands) else None
+    strong = args.scaling == "strong"
+    out = {"metric": "cg_iters_per_sec", "value": best["value"] if best else None, "unit": "iters/s", "n_gpus": args.gpus,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": best["ms_per_step"] if best else None, "higher_is_better": True,
+           "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    if best:
+        n, U = best["n"], best["unknowns"]
+        U1 = unknowns(args.n)
+        out["config"] = {
+            "workload": (f"{n}x{n} L-shaped Dirichlet Poisson fp64 cut into {args.gpus} parts, matrix-free CG, fixed {args.steps} iterations" if strong else
+                         f"{n}x{n} L-shaped Dirichlet Poisson fp64 over {args.gpus} parts of ~{U1} unknowns (config-2 size per GPU), matrix-free CG, fixed {args.steps} iterations"),
+            "n": n, "unknowns": U, "unknowns_per_gpu": U / args.gpus, "rule": args.rule,
+            "value_is": ("global CG iterations/s" if strong else "global CG iterations/s x (unknowns / config-2 unknowns) = config-2-sized part iterations/s") +
+                        f"; median of {best['repeats']} timed solves of {args.steps} iterations, max over ranks",
+            "decomposition": best["decomposition"],
+            "parallelism": f"{'(N/2) x 2 blocks' if args.decomp == '2d' else 'row slabs'} x{args.gpus}, one process per GPU, leg '{best['leg']}': {best['what']}"}
+        out["headline_leg"] = best["leg"]
+        out["rccl_nranks"] = best["transport"].get("rccl_nranks")
+        out["global_iters_per_sec"] = best["global_iters_per_sec"]
+        out["ms_per_step_min_max"] = best["ms_per_step_min_max"]
+        out["hbm_gbps"] = best["hbm_gbps"]
+        out["hbm_gbps_is"] = f"bytes really moved, summed over GPUs: {8.0 * sum(WORDS[args.rule].values()):.0f} B per unknown per iteration"
+        out["algorithmic_equivalent_gbps_88B"] = round(SURVEY_BYTES_PER_UNKNOWN * U * best["global_iters_per_sec"] / 1e9, 1)
+        out["phases_ms"] = best["phases_ms"]
+        out["verify_against_one_gpu"] = best["verify_against_one_gpu"]
+        # whole-iteration roofline per GPU (kernels + record hops + halo + driver); the per-kernel figures are in the 1-GPU bench line
+        out["roofline"] = {"bound": "hbm", "achieved": best["per_gpu_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": best["per_gpu_frac_of_8000"],
+                           "traffic": None, "scope": "bytes one GPU has to move per iteration / wall time per iteration, record hops and halo included"}
+    else:
+        out["error"] = "no leg of the requested configuration produced a record"
+    out["legs"] = results
+    if notes:
+        out["notes"] = notes
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def bench_one_gpu(args, emit):
     import torch
     import iterative_solvers_amd as isa
     from iterative_solvers_amd import _capi
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     rule = _capi.RULE_REL_2NORM if args.rule == "rel2" else _capi.RULE_MSG_MAXNORM
-
-    if world > 1 or args.gpus > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1":
-        out = bench_team(args, rule)
-        wd.cancel()
-        if rank == 0:
-            emit(out)
-        return
-
     n = args.n
     U = unknowns(n)
     f32 = args.dtype == "f32"
@@ -268,21 +427,27 @@ def main():
         return h.solve(p)
 
     run(args.warmup, False)                                   # untimed warm-up iterations
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = run(args.steps, False)                              # exactly K iterations (plus the initialisation pass of a solve)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert res.iterations == args.steps, (res.iterations, args.steps)
+    # R timed solves of exactly K iterations each (plus the initialisation pass of a solve), back to back; the median is the value
+    times, loops = [], []
+    for _ in range(repeats(args, 0.14 * max(1.0, U / 12.6e6) * (0.5 if f32 else 1.0))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run(args.steps, False)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        loops.append(res.loop_seconds)
+        assert res.iterations == args.steps, (res.iterations, args.steps)
+    dt = median(times)
     its = args.steps / dt
-    its_loop = args.steps / res.loop_seconds if res.loop_seconds > 0 else None     # HIP events around the K iterations alone
+    loop = median(loops)
+    its_loop = args.steps / loop if loop > 0 else None        # HIP events around the K iterations alone
 
     words = WORDS[args.rule]
     words_iter = sum(words.values())
     roofline = None
     if not args.no_roofline_pass:
         # same loop again with a HIP-event pair around every launch on the solve stream
-        k = min(args.steps, 500)
+        k = min(max(args.steps, 200), 500)
         run(k, True)
         t = {name: h.kernel_time(i) for i, name in enumerate(("stencil", "update"))}
         dom = max(t, key=lambda name: t[name][0] * t[name][1])
@@ -293,7 +458,10 @@ def main():
         kname = {"stencil": "k_stencil", "update": "k_update_st"}[dom]
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_6290": round(achieved / 6290.0, 4),
-                    "traffic": (tr or {}).get(dom), "avg_ms": round(ms, 5), "launches": launches,
+                    "traffic": (tr or {}).get(dom),
+                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (gfx950 correction applied), not measured in this run" if tr else None,
+                    "avg_ms": round(ms, 5), "launches": launches,
+                    "avg_ms_is": "mean of HIP-event pairs around each launch on the solve stream (the pairs add a little: their sum exceeds loop_only_ms_per_step)",
                     "alg_bytes_per_launch": alg, "alg_words_per_unknown": words[dom],
                     "words_per_unknown_per_iteration": words_iter, "alg_words": words,
                     "other": {name: {"avg_ms": round(t[name][0], 5),
@@ -306,10 +474,12 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{n}x{n} L-shaped Dirichlet Poisson {'fp32 inner CG of the mixed-precision path' if f32 else 'fp64'}, matrix-free CG, fixed {args.steps} iterations",
                    "n": n, "unknowns": U, "rule": args.rule, "layout": h.layout()},
-        "timing": "host clock around one solve of K iterations between device synchronisations (includes the solve's initialisation pass: "
-                  "one pass x = 0, r = b, z = 0, ||r0||, and the last poll ~ 0.2 ms); loop_only_* = HIP events around the K iterations on the solve stream",
+        "timing": f"median of {len(times)} back-to-back solves of K iterations each, host clock between device synchronisations (each includes the solve's "
+                  "initialisation pass: one pass x = 0, r = b, z = 0, ||r0||, and the last poll ~ 0.2 ms); loop_only_* = HIP events around the K iterations on the solve stream",
+        "repeats": len(times),
+        "value_min_max": [round(args.steps / max(times), 2), round(args.steps / min(times), 2)],
         "loop_only_iters_per_sec": round(its_loop, 2) if its_loop else None,
-        "loop_only_ms_per_step": round(1e3 * res.loop_seconds / args.steps, 5) if its_loop else None,
+        "loop_only_ms_per_step": round(1e3 * loop / args.steps, 5) if its_loop else None,
         # bytes the iteration really moves in this implementation: never above the HBM pin rate
         "hbm_gbps": round(words_iter * wbytes * U * its / 1e9, 1),
         "hbm_gbps_is": f"bytes really moved: {words_iter} words = {words_iter * wbytes:.0f} B per unknown per iteration",
@@ -320,8 +490,63 @@ def main():
     }
     if args.cpu_iters > 0 and not f32:
         out["cpu_baseline"] = cpu_baseline(n, args.cpu_iters)
-    wd.cancel()
     emit(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--grid", dest="n", type=int, default=4096, help="grid intervals per side (per GPU for weak scaling)")
+    ap.add_argument("--rule", choices=["rel2", "msg"], default="rel2")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64",
+                    help="f32 = BASELINE config 3: the fp32-storage inner CG of the mixed-precision path (use --grid 8192)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: weak (part size fixed) or strong (--grid fixed)")
+    ap.add_argument("--decomp", choices=["rows", "2d"], default="rows", help="N > 1: row slabs or (N/2) x 2 blocks")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--repeats", type=int, default=0, help="timed solves of K iterations each, the median is reported (0 = 11, fewer for long solves)")
+    ap.add_argument("--verify", type=int, default=30, help="N > 1: iterations of the untimed cross-check against one GPU (0 = skip)")
+    ap.add_argument("--verify-max-unknowns", type=float, default=2.6e8, help="skip that cross-check above this size (host set-up time)")
+    ap.add_argument("--legs", default="all", help="N > 1: all | default (the two headline transports only) | comma-separated leg names")
+    ap.add_argument("--leg-timeout", type=float, default=240.0, help="seconds after which the processes of one leg are killed")
+    ap.add_argument("--budget", type=float, default=900.0, help="seconds after which no further leg is started")
+    ap.add_argument("--child-leg", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-out", default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.child_leg:                                            # a rank process of one leg
+        import threading
+        wd = threading.Timer(args.leg_timeout + 30.0, lambda: os._exit(3))     # last resort: never outlive the coordinator's patience
+        wd.daemon = True
+        wd.start()
+        child_main(args)
+        return
+
+    # ONE JSON line on stdout: libraries chat there too (RCCL prints a version banner when its first communicator comes up),
+    # so everything else this process writes to fd 1 goes to stderr until the line is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(obj), flush=True)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1 or os.environ.get("MI355CG_BENCH_DIST") == "1":
+        got = coordinate(args)                                     # before anything could touch a GPU in this process
+        if got is None:
+            return                                                 # a non-zero rank's coordinator: rank 0 prints
+        out = compose(args, *got)
+        assert out["n_gpus"] == args.gpus
+        emit(out)
+        if out.get("value") is None:
+            sys.exit(4)
+        return
+    bench_one_gpu(args, emit)
 
 
 if __name__ == "__main__":

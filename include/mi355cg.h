@@ -195,9 +195,14 @@ int  mi355cg_dist_halo_recv_counts(mi355cg_handle h, long long *n_from_lo, long 
  * A team = a decomposition of the grid into `world` parts + a transport.  MI355CG_DECOMP_ROWS: row slabs balanced by
  * unknown count.  MI355CG_DECOMP_2D: (world/2) x 2 blocks -- BASELINE config 4's "2 x 2" for world = 4: y-cuts where the
  * slabs hold equal unknowns, every slab cut in x where ITS unknowns halve, x-cuts on 128-column strip boundaries.
- * Per iteration a part exchanges its 16-double record of partial sums twice (all-gather) and the boundary rows / columns
- * of the residual once (neighbour messages, overlapped with the interior launches on a second stream); results are
- * bit-identical to the single-GPU solve for every decomposition.  The reference has no counterpart (single process,
+ * Per iteration every part needs every part's 16-double record of partial sums twice, and its neighbours' boundary rows /
+ * columns of the residual once.  Default transport: the producer launch's last block stores the record straight into every
+ * part's mailbox (peer memory over xGMI, IPC-mapped across processes) and the consumer launch polls its own mailbox; the
+ * halo is pushed into the neighbours' ghost cells by one small launch and announced with a stream-ordered 64-bit write.
+ * RCCL (ncclAllGather / ncclSend / ncclRecv) carries the bootstrap and is the fallback for both (environment:
+ * MI355CG_TEAM_RECORDS = auto | rccl | mailbox | events, MI355CG_TEAM_WAIT = auto | kernel | stream, MI355CG_TEAM_HALO = auto |
+ * inline | stream | push, MI355CG_TEAM_TIMEOUT_MS; mi355cg_team_describe says what a team uses).  Results are bit-identical to
+ * the single-GPU solve for every decomposition and transport.  The reference has no counterpart (single process,
  * solver/solver.hpp:13 HostSpace only); the entry points mirror mi355cg_create / mi355cg_solve.                          */
 #define MI355CG_DECOMP_ROWS 0
 #define MI355CG_DECOMP_2D   1
@@ -228,11 +233,17 @@ int  mi355cg_team_unique_id(void *id128);
 int  mi355cg_team_create_rccl(int n, int m, double a, double b, double c, double d, int world, int rank, int device,
                               const void *id128, int decomp, mi355cg_team *out);
 void mi355cg_team_destroy(mi355cg_team t);
-/* as mi355cg_solve (no per-iteration diagnostics).  Collective over the team: every rank calls it with the same params.
- * A stop request on any rank stops all of them at the same iteration (it travels with the next update record).          */
+/* as mi355cg_solve (no per-iteration diagnostics).  Collective over the team: every rank calls it with the same params; the
+ * callback and the stop flag may differ from rank to rank (the schedule of launches, polls and collectives depends on the
+ * parameters only).  A stop request on any rank travels with that rank's next update record and every rank takes the decision
+ * INTERRUPTED in the same iteration (msg_solver.cpp:82-87).  A record that does not arrive within MI355CG_TEAM_TIMEOUT_MS
+ * (30 s) ends the solve with MI355CG_ERR_STATE on every rank instead of a hang; the team cannot be used after that.        */
 int  mi355cg_team_solve(mi355cg_team t, const mi355cg_params *params, mi355cg_iter_cb cb, void *user,
                         const volatile int *stop_flag, mi355cg_results *out);
 int  mi355cg_team_info(mi355cg_team t, int *world, int *nlocal, int *decomp, long long *size);
+/* "transport=rccl records=mailbox wait=kernel halo=push split=0 ipc=1 shared_device=0 rccl_nranks=8 rccl_lib=...": what the next
+ * solve of this team uses (rccl_nranks = what ncclCommCount reports for the team's communicator; 0 for a LOCAL team)        */
+int  mi355cg_team_describe(mi355cg_team t, char *buf, int len);
 int  mi355cg_team_part(mi355cg_team t, int local_index, mi355cg_handle *part, int *rank);
 /* which as in mi355cg_checksum.  get_vector fills the entries of the caller's GLOBAL packed vector (length size) owned by
  * this process's parts; checksum covers this process's parts.                                                           */

@@ -102,7 +102,8 @@ struct CgState {
     double r0norm;      // ||r0||_2
     double rnorm2;      // ||r||_2
     double rmax, dmax, emax, d2, e2;
-    int it, done, reason, converged, first, pad_;
+    int it, done, reason, converged, first;
+    int stop;           // a stop request was pending when the last update launch ended (single context: read from the pinned word; msg_solver.cpp:82-87)
     double alpha_hist[kRing];   // step length of iteration k at [k % kRing]: the folded x update (XM >= 2) applies up to kRing - 1 earlier steps at once
 };
 struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2, tr2; };   // tr2: ||b - A x||_2^2 (REL_2NORM diagnostics mode, written by k_resid2_hist)
@@ -113,7 +114,7 @@ struct HistEntry { double dmax, rmax, emax, rnorm2, d2, e2, tr2; };   // tr2: ||
 // median wave waited 10-14 us of a 65 us launch for its copy of the state (tools/wave_timing.py, profiles/r01_tune_notes.md).
 // Safe because no kernel writes the state object it reads (s_in != s_out) and the scalar cache is invalidated at
 // every kernel start.
-struct StateLite { double alpha, rr, rr_prev, rz, r0norm; int it, done, first; };
+struct StateLite { double alpha, rr, rr_prev, rz, r0norm; int it, done, first, stop; };
 template <typename V> __device__ inline V scalar_load(const V* p) {
     return *(const __attribute__((address_space(4))) V*)p;
 }
@@ -124,7 +125,7 @@ __device__ inline StateLite load_state_lite(const CgState* p) {
     StateLite L;
     L.alpha = scalar_load(&p->alpha); L.rr = scalar_load(&p->rr); L.rr_prev = scalar_load(&p->rr_prev);
     L.rz = scalar_load(&p->rz); L.r0norm = scalar_load(&p->r0norm);
-    L.it = scalar_load(&p->it); L.done = scalar_load(&p->done); L.first = scalar_load(&p->first);
+    L.it = scalar_load(&p->it); L.done = scalar_load(&p->done); L.first = scalar_load(&p->first); L.stop = scalar_load(&p->stop);
     return L;
 }
 
@@ -267,8 +268,11 @@ __device__ inline dd reduce_parts_dd(const double* __restrict__ part_hi, const d
 // evaluates it from the same reduced numbers, so all blocks agree.
 struct Decision { int done, reason, converged; double beta, rr, rnorm2, r0norm, rmax, dmax, emax, d2, e2; };
 
+// `stop`: a stop request is pending (this context's pinned word as sampled by the last update launch, or the max over the
+// parts' records of a team).  It is looked at AFTER the convergence tests of the iteration just finished, i.e. where the
+// reference's loop tests its flag: at the top of the next iteration (msg_solver.cpp:82-87).
 __device__ inline Decision decide_after_update(const StateLite& s, const RuleParams& rp, double rr, double rmax,
-                                               double dmax, double emax, double d2, double e2) {
+                                               double dmax, double emax, double d2, double e2, bool stop = false) {
     Decision d;
     d.rr = rr; d.rnorm2 = sqrt(rr); d.rmax = rmax; d.dmax = dmax; d.emax = emax; d.d2 = d2; d.e2 = e2;
     d.r0norm = s.first ? d.rnorm2 : s.r0norm;
@@ -287,6 +291,7 @@ __device__ inline Decision decide_after_update(const StateLite& s, const RulePar
         if (!d.done && !(s.it < rp.max_iterations)) d.done = 1;                         // while (it < maxIterations) :80
         if (!s.first) d.beta = (d.rnorm2 * d.rnorm2) / s.rz;                            // :165
     }
+    if (!d.done && (stop || s.stop)) { d.done = 1; d.reason = 4 /*INTERRUPTED*/; d.converged = 0; }   // msg_solver.cpp:82-87
     return d;
 }
 
@@ -331,19 +336,66 @@ __device__ inline Decision reduce_and_decide(const StateLite& s, const RuleParam
 // Record = the part's partials reduced in slot order (sums as hi/lo pairs, then the maxes) + its stop request: what
 // crosses parts after each phase.  Producing it in the producer launch itself (arrival ticket, last arriver reduces)
 // instead of a separate one-block launch takes a launch boundary and a kernel off the critical path
-// producer -> record -> all-gather -> consumer.
+// producer -> record -> consumer.
+//
+// A record travels in FLAGGED form: its 16 doubles are cut into 32 words of 32 data bits, each stored as one 64-bit word
+// {stamp << 32 | data} with a single-copy-atomic system-scope store.  A consumer knows a word has arrived when it carries
+// the stamp it expects (the team-wide iteration sequence number), so no fence orders the words with anything: the
+// producer's last block stores them straight into the mailbox of every part (its own GPU's memory, a peer GPU's over
+// xGMI, another process's through an IPC mapping) and the consumer launch polls its LOCAL mailbox in its prologue.
+// That is the whole hop: no collective, no event, no second launch.  (RCCL's LL protocol is the same idea; with the RCCL
+// all-gather as the transport the flagged words are what is gathered and the poll succeeds at once.)
+typedef unsigned long long u64;
 constexpr int kRecWords = 16;                     // doubles per record
+constexpr int kLLWords = 2 * kRecWords;           // 64-bit flagged words per record
 constexpr int kRecStopWord = 9;                   // word that carries a rank's stop request (max over ranks = stop everywhere)
 constexpr int kMaxRecDst = 16;
+constexpr int kReasonTransport = 5;               // internal stop reason: a record did not arrive within the budget (-> MI355CG_ERR_STATE)
+__device__ inline u64 ld_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline void st_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 struct RecSpec {
     int enabled;                                  // 0: this launch does not end a phase of a team
     int nslots;                                   // partial slots of the whole phase (interior + edge launches)
     unsigned* ticket;                             // arrival counter, 0 between launches
     const int* stop_req;                          // pinned host word (update phase), may be null
     int ndst;
-    double* const* dst;                           // DEVICE array: this part's slot in the gathered buffer of every part this process drives
+    u64* const* dst;                              // DEVICE array: this part's record (slot 0) in the mailbox of every destination part
                                                   // (an array inside the by-value kernel arguments would be spilled as soon as it is indexed at run time)
+    u64* const* flag;                             // DEVICE array or null: per destination, the word a STREAM-level wait of the consumer watches
+    int slot_words;                               // 64-bit words from slot 0 to slot 1 of a mailbox
+    int slot;                                     // the slot of this record (iteration sequence number & 1)
+    unsigned seq;                                 // stamp of this record (never 0)
+    u64 flag_value;                               // what the announcement words get: the sequence number itself
 };
+// Where a consumer launch finds the records of the phase before it.
+struct RecSrc {
+    const u64* mbox;                              // [world][kLLWords] (the slot this launch reads); nullptr: legacy per-block partials
+    int world;
+    unsigned stamp;
+    u64 budget;                                   // wall_clock64 ticks (100 MHz) this launch may wait for a word
+};
+// All threads of a block.  recs: LDS, [world][kRecWords] doubles.  Returns false when a word did not show up in time.
+__device__ inline bool gather_records(const RecSrc& src, double* recs) {
+    unsigned* out = reinterpret_cast<unsigned*>(recs);
+    const int n = src.world * kLLWords;
+    int bad = 0;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        u64 v = ld_sys(src.mbox + i);
+        if ((unsigned)(v >> 32) != src.stamp) {
+            const u64 t0 = wall_clock64();
+            unsigned spins = 0;
+            for (;;) {
+                __builtin_amdgcn_s_sleep(2);
+                v = ld_sys(src.mbox + i);
+                if ((unsigned)(v >> 32) == src.stamp) break;
+                if ((++spins & 31u) == 0 && wall_clock64() - t0 > src.budget) { bad = 1; break; }
+            }
+        }
+        out[i] = (unsigned)v;                     // word 2k + h of a record = half h of its double k (little endian)
+    }
+    return __syncthreads_or(bad) == 0;
+}
 // A block's partial: a plain store, or -- when another block of the SAME launch will read it (team record) -- a
 // write-through store at agent scope (cdna_hip_programming.md Guideline 16, R1: sc1 payload, drain, ticket; NO release
 // fence: on this 8-XCD part an agent-scope release writes back the whole dirty L2, i.e. the launch's own output stream,
@@ -352,12 +404,22 @@ __device__ inline void store_partial(double* p, double v, bool publish) {
     if (publish) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
+// rec (LDS, kRecWords doubles) -> flagged words in every destination's mailbox
+__device__ inline void publish_record(const double* rec, const RecSpec& rs) {
+    const unsigned* half = reinterpret_cast<const unsigned*>(rec);
+    const long long slot = (long long)rs.slot * rs.slot_words;
+    for (int i = threadIdx.x; i < rs.ndst * kLLWords; i += kBlock)
+        st_sys(rs.dst[i / kLLWords] + slot + i % kLLWords, ((u64)rs.seq << 32) | half[i % kLLWords]);
+    if (rs.flag && (int)threadIdx.x < rs.ndst) st_sys(rs.flag[threadIdx.x], rs.flag_value);
+}
 // which: 0 = stencil partials (FA_*), 1 = update partials (FB_*).  Called by all threads of one block.
 // All loads of all fields are issued first (one memory round trip instead of one per field), then reduced field by field
 // in reduce_parts_dd's order.
 __device__ inline void emit_record(int which, const double* part, int stride, const RecSpec& rs, double* lds) {
     __shared__ double rec[kRecWords];
     if (threadIdx.x < kRecWords) rec[threadIdx.x] = 0.0;
+    int stop_word = 0;                            // a read of pinned HOST memory: issued first, so it travels beside the partial loads
+    if (which == 1 && threadIdx.x == 0 && rs.stop_req) stop_word = *(const volatile int*)rs.stop_req;
     const int nsum = which == 0 ? kNumSumsA : kNumSumsB, lo_off = which == 0 ? FA_LO : FB_LO;
     constexpr int kMaxSums = 3;
     PreParts pre[kMaxSums];
@@ -380,13 +442,10 @@ __device__ inline void emit_record(int which, const double* part, int stride, co
             const double t = reduce_max_pre(pmax[k], part + (FB_RMAX + k) * stride, rs.nslots, 1, lds);
             if (threadIdx.x == 0) rec[FB_RMAX + k] = t;
         }
-        if (threadIdx.x == 0 && rs.stop_req) rec[kRecStopWord] = *(const volatile int*)rs.stop_req ? 1.0 : 0.0;
+        if (threadIdx.x == 0) rec[kRecStopWord] = stop_word ? 1.0 : 0.0;
     }
     __syncthreads();
-    // the destinations may be another GPU's memory (LOCAL team over peer access): system-scope write-through stores
-    for (int i = threadIdx.x; i < rs.ndst * kRecWords; i += kBlock)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rs.dst[i / kRecWords] + i % kRecWords),
-                           __builtin_bit_cast(unsigned long long, rec[i % kRecWords]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    publish_record(rec, rs);
 }
 // Epilogue of a producer launch; thread 0 has just stored this block's partials with store_partial(..., true).
 // Returns after the last block emitted the record.
@@ -403,6 +462,42 @@ __device__ inline void arrive_and_record(int which, const double* part, int stri
     emit_record(which, part, stride, rs, lds);
     if (threadIdx.x == 0) __hip_atomic_store(rs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- the consumer side: the phase's scalars from the parts' records, in part order -------------------------------
+__device__ inline Decision decide_from_records(const StateLite& s, const RuleParams& rp, const double* recs, int world) {
+    dd rr = dd_zero(), d2 = dd_zero(), e2 = dd_zero();
+    double rmax = 0, dmax = 0, emax = 0, stop = 0;
+    for (int j = 0; j < world; ++j) {
+        const double* R = recs + j * kRecWords;
+        rr = dd_add(rr, dd{R[FB_RR], R[FB_RR + FB_LO]});
+        d2 = dd_add(d2, dd{R[FB_D2], R[FB_D2 + FB_LO]});
+        e2 = dd_add(e2, dd{R[FB_E2], R[FB_E2 + FB_LO]});
+        rmax = fmax(rmax, R[FB_RMAX]); dmax = fmax(dmax, R[FB_DMAX]); emax = fmax(emax, R[FB_EMAX]);
+        stop = fmax(stop, R[kRecStopWord]);
+    }
+    return decide_after_update(s, rp, dd_value(rr), rmax, dmax, rp.use_u ? emax : 0.0, dd_value(d2), rp.use_u ? dd_value(e2) : 0.0, stop > 0.0);
+}
+__device__ inline void alpha_from_records(const StateLite& s, int rule, const double* recs, int world, double* alpha, double* rz_out) {
+    dd pap = dd_zero(), rz = dd_zero();
+    for (int j = 0; j < world; ++j) {
+        const double* R = recs + j * kRecWords;
+        pap = dd_add(pap, dd{R[FA_PAP], R[FA_PAP + FA_LO]});
+        rz = dd_add(rz, dd{R[FA_RZ], R[FA_RZ + FA_LO]});
+    }
+    if (rule == 0) { *rz_out = dd_value(rz); *alpha = *rz_out / dd_value(pap); }       // msg_solver.cpp:102
+    else { *rz_out = 0.0; *alpha = s.rr / dd_value(pap); }                             // matrix_free_system.cpp:419
+}
+// A producer launch that ends in its prologue (the solve is over) publishes no record, but consumers whose STREAMS wait for the
+// announcement word of this phase (WAIT_STREAM) were enqueued regardless: one thread announces without a record.  The consumer
+// launches behind those waits return in their own prologue before they look at the mailbox.
+__device__ inline void announce_only(const RecSpec& rs) {
+    if (!rs.enabled || !rs.flag) return;
+    for (int d = 0; d < rs.ndst; ++d) st_sys(rs.flag[d], rs.flag_value);
+}
+// a launch whose records did not arrive: the solve ends here with an internal reason the host turns into an error
+__device__ inline void fail_transport(CgState* out, const CgState* in) {
+    copy_state(out, in);
+    out->done = 1; out->reason = kReasonTransport; out->converged = 0;
+}
 
 // ---- phase A': fused direction update + 5-point stencil + dots ------------------------------------
 template <typename T>
@@ -414,6 +509,7 @@ struct StencilArgs {
     T* pout;             // FUSED: new direction (ping-pong partner of pin)
     T* ap;               // PLAIN: A_h * input vector
     const double* partB; int nB, strideB, esB;  // update-kernel partials to reduce in the prologue (count, field stride, element stride)
+    RecSrc src;                                 // team: the parts' update records instead (src.mbox != nullptr)
     double* partA; int strideA, slotA;          // this kernel's partials (field-major); first slot of this launch
     const CgState* s_in; CgState* s_out;        // state written by the update kernel / by this kernel
     HistEntry* hist;
@@ -627,7 +723,19 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
 
     T beta = (T)0;
-    if (FUSED) {
+    if (FUSED && a.src.mbox) {
+        // team: the decision comes from the parts' records (one poll of the local mailbox), not from per-block partials
+        __shared__ double recs[kMaxRecDst * kRecWords];
+        const StateLite s = load_state_lite(a.s_in);
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) { copy_state(a.s_out, a.s_in); announce_only(a.rec); } return; }
+        MI355CG_WT_STAMP(1)
+        if (!gather_records(a.src, recs)) { if (blockIdx.x == 0 && threadIdx.x == 0) { fail_transport(a.s_out, a.s_in); announce_only(a.rec); } return; }
+        const Decision d = decide_from_records(s, a.rp, recs, a.src.world);
+        MI355CG_WT_STAMP(2)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { write_state_after_decision(a.s_out, a.hist, a.s_in, s, d); if (d.done) announce_only(a.rec); }
+        if (d.done) return;
+        beta = (T)d.beta;
+    } else if (FUSED) {
         const PreParts pre = prefetch_parts(a.partB + FB_RR * a.strideB, a.partB + (FB_RR + FB_LO) * a.strideB, a.nB, a.esB);
         PreMax pmax[3] = {{0, 0}, {0, 0}, {0, 0}};
         if (MSG) {
@@ -913,10 +1021,12 @@ struct UpdateStArgs {
     const T* pprev[kRing - 1];   // XM >= 2: the directions of the 1, 2, ... iterations before (the other buffers of the ring)
     T* r; T* x; const T* u;
     const double* partA; int nA, strideA, esA;
+    RecSrc src;          // team: the parts' stencil records instead (src.mbox != nullptr)
     double* partB; int strideB, slotB;
     const CgState* s_in; CgState* s_out;
     int rule;
     int reverse;         // take the items from the last to the first (start where the stencil launch ended)
+    const int* stop_req; // single context: pinned host word, sampled once per iteration by block 0 -> CgState::stop (msg_solver.cpp:82-87); may be null
     RecSpec rec;         // team: this launch ends the update phase -> its last block writes the part's record
 };
 
@@ -930,6 +1040,10 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const ItemSeq seq = item_seq(a.wl, wave);
     MI355CG_WT_BEGIN
+    // single context: the stop request (a pinned HOST word) is sampled once per iteration by block 0 -- a scalar load issued
+    // here and consumed in the epilogue, so its PCIe round trip runs under the whole launch
+    int stop_word = 0;
+    if (blockIdx.x == 0 && a.stop_req) stop_word = scalar_load(a.stop_req);
     constexpr bool FULL = XM == 1;
     constexpr int NP = XM >= 2 ? XM - 1 : 0;          // earlier directions folded into this launch's x update
     struct Raw { vec_t p, r, x, u, pp[NP > 0 ? NP : 1]; T pe; };
@@ -998,13 +1112,20 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) q[k] = fetch();
 
-    const PreParts pre = prefetch_parts(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA);
-    PreParts pre_rz{0, 0, 0, 0};
-    if (FULL) pre_rz = prefetch_parts(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA);
-    const StateLite s = load_state_lite(a.s_in);
-    if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
     double alpha_d, rz = 0.0;
-    {
+    StateLite s;
+    if (a.src.mbox) {
+        __shared__ double recs[kMaxRecDst * kRecWords];
+        s = load_state_lite(a.s_in);
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) { copy_state(a.s_out, a.s_in); announce_only(a.rec); } return; }
+        if (!gather_records(a.src, recs)) { if (blockIdx.x == 0 && threadIdx.x == 0) { fail_transport(a.s_out, a.s_in); announce_only(a.rec); } return; }
+        alpha_from_records(s, a.rule, recs, a.src.world, &alpha_d, &rz);
+    } else {
+        const PreParts pre = prefetch_parts(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA);
+        PreParts pre_rz{0, 0, 0, 0};
+        if (FULL) pre_rz = prefetch_parts(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA);
+        s = load_state_lite(a.s_in);
+        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) copy_state(a.s_out, a.s_in); return; }
         const double pap = dd_value(reduce_parts_dd_pre(pre, a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA, lds));
         if (a.rule == 0) {
             rz = FULL ? dd_value(reduce_parts_dd_pre(pre_rz, a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, a.esA, lds))
@@ -1110,6 +1231,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
             copy_state(a.s_out, a.s_in);
             CgState* o = a.s_out;
             o->it = s.it + 1; o->first = 0; o->alpha = alpha_d; o->rz = rz; o->alpha_hist[(s.it + 1) & (kRing - 1)] = alpha_d;
+            o->stop = stop_word != 0;              // the reference tests its flag once per iteration (msg_solver.cpp:82-87)
         }
     }
     arrive_and_record(1, a.partB, a.strideB, a.rec, lds);
@@ -1118,6 +1240,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
 // ---- end-of-chunk check: same decision as the next stencil prologue, without advancing -------------
 struct CheckArgs {
     const double* partB; int nB, strideB, esB;
+    RecSrc src;               // team: the parts' update records instead
     const CgState* s_in;      // state written by the last update kernel
     CgState* summary;         // device copy that the host reads
     HistEntry* hist;
@@ -1128,7 +1251,12 @@ __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
     __shared__ double lds[2 * kWaves];
     const StateLite s = load_state_lite(a.s_in);
     if (s.done) { if (threadIdx.x == 0) copy_state(a.summary, a.s_in); return; }
-    const Decision d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, 1, lds);
+    Decision d;
+    if (a.src.mbox) {
+        __shared__ double recs[kMaxRecDst * kRecWords];
+        if (!gather_records(a.src, recs)) { if (threadIdx.x == 0) fail_transport(a.summary, a.s_in); return; }
+        d = decide_from_records(s, a.rp, recs, a.src.world);
+    } else d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, 1, lds);
     if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, a.s_in, s, d);
 }
 

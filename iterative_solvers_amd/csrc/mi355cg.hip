@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mi355cg;
@@ -92,6 +93,8 @@ struct mi355cg_ctx {
     bool dist_active = false, is_slab = false;
     CgState *sA = nullptr, *sB = nullptr, *summary = nullptr;
     unsigned* ticket = nullptr;         // arrival counter of the launch that writes a team record (RecSpec)
+    int* stop_h = nullptr;              // pinned host word: a stop request, sampled by block 0 of every update launch (msg_solver.cpp:82-87)
+    int* stop_dev = nullptr;            // the same word as the device addresses it (nullptr while no solve with a stop flag is running)
     HistEntry* hist = nullptr;
     CgState* summary_h = nullptr;       // pinned
     HistEntry* hist_h = nullptr;        // pinned
@@ -112,6 +115,7 @@ struct mi355cg_ctx {
     struct ChunkGraph { int m, cur; std::vector<char> flags; hipGraphExec_t exec; };
     std::vector<ChunkGraph> graphs;
     mi355cg_params graph_prm{};          // parameters the cached graphs were captured with
+    bool graph_stop = false;            // ... and whether those solves sampled the stop word
     int use_graph = -1;                 // env MI355CG_GRAPH: -1 auto (small grids), 0 off, 1 on
 
     hipEvent_t ev_loop[2] = {nullptr, nullptr};   // brackets the iterations of the last solve (mi355cg_results::loop_seconds)
@@ -303,7 +307,7 @@ int flat_grid(long long n) { return (int)std::max<long long>(1, std::min<long lo
 // ---- launchers -------------------------------------------------------------------------------------
 // Where a consumer kernel finds the partials it reduces in its prologue: the producer kernel's own
 // field-major array (estride 1) or partials all-gathered across ranks, rank-major (estride = #fields).
-struct PartSrc { const double* ptr; int n, fstride, estride; };
+struct PartSrc { const double* ptr; int n, fstride, estride; RecSrc rec; };     // rec.mbox != nullptr (teams): the parts' records instead of partials
 // Which items a launch covers, where it runs, and the first partial slot it writes.
 struct Where { hipStream_t stream; const Plan* plan; int slot; };
 
@@ -332,7 +336,7 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
     StencilArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
     a.r = r; a.pin = p[c->cur]; a.pout = p[(c->cur + 1) % c->xsteps]; a.ap = nullptr;
-    a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
+    a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride; a.src = pb.rec;
     a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slot;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     a.store_ghosts = c->is_slab ? 1 : 0;
@@ -358,10 +362,11 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
     a.p = p[c->cur]; a.r = r; a.x = x; a.u = u;
     for (int i = 0; i < kRing - 1; ++i) a.pprev[i] = p[(c->cur + 2 * kRing * c->xsteps - 1 - i) % c->xsteps];      // directions of iterations k-1, k-2, ...
-    a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride;
+    a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride; a.src = pa.rec;
     a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slot;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
     if (rec) a.rec = *rec;
+    else a.stop_req = c->stop_dev;                // single context: block 0 samples the pinned stop word every iteration (a team's travels in its records)
     const dim3 grid(w.plan->grid), block(kBlock);
     const bool d3 = c->depth == 3 && !(cfg.x2 && c->cur == 0 && c->xsteps == 8);
 #define MI355CG_UST(XM, HASU) do { if (d3) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 3, true>), grid, block, 0, w.stream, a); \
@@ -402,7 +407,7 @@ void launch_flush_x(const mi355cg_ctx* c, const Plan& plan, T* x, T* const p[kRi
 
 void launch_check(mi355cg_ctx* c, const IterCfg& cfg, hipStream_t stream, const PartSrc& pb) {
     CheckArgs a{};
-    a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride;
+    a.partB = pb.ptr; a.nB = pb.n; a.strideB = pb.fstride; a.esB = pb.estride; a.src = pb.rec;
     a.s_in = c->sB; a.summary = c->summary; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     hipLaunchKernelGGL(k_check, dim3(1), dim3(kBlock), 0, stream, a);
 }
@@ -817,6 +822,8 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
     hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
     if (hipMalloc((void**)&c->ticket, sizeof(unsigned)) != hipSuccess || hipMemset(c->ticket, 0, sizeof(unsigned)) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "ticket allocation failed"); return cleanup(); }
+    if (hipHostMalloc((void**)&c->stop_h, sizeof(int)) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "stop word allocation failed"); return cleanup(); }
+    *c->stop_h = 0;
     // The zero-fills above run on the NULL stream and are asynchronous to the host; the context's own stream is
     // non-blocking and does not order with them.  Without this wait a delayed memset can land AFTER the first upload
     // or kernel of the context and wipe it (seen as a right-hand side of zeros -> "converged" at iteration 0).
@@ -935,6 +942,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (c->summary_h) hipHostFree(c->summary_h);
     if (c->hist_h) hipHostFree(c->hist_h);
     if (c->partR_h) hipHostFree(c->partR_h);
+    if (c->stop_h) hipHostFree(c->stop_h);
     clear_graphs(c);
     c->events.destroy();
     for (hipEvent_t e : c->ev_loop) if (e) hipEventDestroy(e);
@@ -1070,12 +1078,29 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     }
     HIPCK(hipGetLastError());
 
+    // The stop request: the reference tests its flag at the top of EVERY iteration (msg_solver.cpp:82-87).  Here block 0 of every
+    // update launch samples a pinned word and the next stencil prologue turns it into INTERRUPTED, so a request is honoured at the
+    // next iteration boundary of the DEVICE, however many iterations the host has already queued.  The caller's flag lives in
+    // ordinary host memory; while this thread waits for a chunk it forwards the flag to the pinned word.
+    *c->stop_h = 0;
+    c->stop_dev = nullptr;
+    if (stop_flag) HIPCK(hipHostGetDevicePointer((void**)&c->stop_dev, c->stop_h, 0));
+    auto wait_stream = [&]() -> int {
+        if (!stop_flag) { HIPCK(hipStreamSynchronize(c->stream)); return MI355CG_OK; }
+        for (;;) {
+            if (*stop_flag) *c->stop_h = 1;
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIPCK(q);
+            std::this_thread::yield();
+        }
+        return MI355CG_OK;
+    };
     auto poll = [&]() -> int {
         launch_check(c, cfg, c->stream, own_partB(c));
         HIPCK(hipMemcpyAsync(c->summary_h, c->summary, sizeof(CgState), hipMemcpyDeviceToHost, c->stream));
         HIPCK(hipMemcpyAsync(c->hist_h, c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(hipStreamSynchronize(c->stream));
-        return MI355CG_OK;
+        return wait_stream();
     };
     // The state of iteration 0 is only fetched when somebody looks at it (the it = 0 callback, msg_solver.cpp:75-77);
     // ||r0|| travels in the state and is read with the last poll.
@@ -1100,7 +1125,9 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     // A caller that watches the solve (callback or stop flag) gets the first iteration on its own: the it == 1 callback
     // is delivered, and a stop requested from it is honoured, before any further work is queued.
     bool first_chunk = cb != nullptr || stop_flag != nullptr;
-    if (std::memcmp(&c->graph_prm, prm, sizeof *prm) != 0) { clear_graphs(c); c->graph_prm = *prm; }     // kernel arguments embed the solve's parameters: graphs live as long as those do
+    if (std::memcmp(&c->graph_prm, prm, sizeof *prm) != 0 || c->graph_stop != (stop_flag != nullptr)) {         // kernel arguments embed the solve's parameters
+        clear_graphs(c); c->graph_prm = *prm; c->graph_stop = stop_flag != nullptr;                                // (and whether the stop word is sampled): graphs live as long as those do
+    }
     const bool graph_ok = !c->profiling && !diag &&
                           (c->use_graph == 1 || (c->use_graph < 0 && c->g.own_len < (4LL << 20) && prm->max_iterations >= 4 * sync_every));
     while (!c->summary_h->done) {
@@ -1166,7 +1193,9 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
                 cb(user, it - 1, std::sqrt(h.d2), std::sqrt(h.tr2), std::sqrt(h.e2));     // matrix_free_system.cpp:466-468 (0-based index)
             } else if (msg) {
                 // callbacks only on iterations that did NOT stop (msg_solver.cpp:172-183 sits after the breaks)
-                const bool stopped_here = c->summary_h->done && c->summary_h->reason != MI355CG_STOP_ITERATIONS && it == it_now;
+                // (an interruption is noticed at the top of the NEXT iteration, :82-87, i.e. after this iteration's callback)
+                const bool stopped_here = c->summary_h->done && c->summary_h->reason != MI355CG_STOP_ITERATIONS &&
+                                          c->summary_h->reason != MI355CG_STOP_INTERRUPTED && it == it_now;
                 if ((it == 1 || (every > 0 && it % every == 0)) && !stopped_here) cb(user, it, h.dmax, h.rmax, cfg.has_u ? h.emax : DBL_MAX);
             }
         }
@@ -1174,6 +1203,8 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     }
     HIPCK(hipEventRecord(c->ev_loop[1], c->stream));
     CgState fin = *c->summary_h;
+    c->stop_dev = nullptr;
+    if (fin.done && fin.reason == MI355CG_STOP_INTERRUPTED) interrupted = true;      // the device saw the request in the middle of a chunk
     // Launches enqueued after the stop decision return in their prologue but still flipped c->cur on the
     // host: the direction of the last REAL iteration is p[it % M] (the solve starts with cur = 0).
     c->cur = fin.it % c->xsteps;

@@ -3,31 +3,41 @@
 // The reference is single-process and has no collectives; this is the scaling surface of the same kernels.
 // A TEAM is a decomposition of the grid into `world` parts -- row slabs balanced by unknown count, or a 2-D split whose
 // x-cuts fall on 128-column strip boundaries -- plus a transport for the two things that cross parts per iteration:
-//   * every part's 16-double record of partial sums / maxes, all-gathered after each of the two launches of an iteration;
+//   * every part's 16-double RECORD of partial sums / maxes / stop request, needed by every part after each of the two
+//     launches of an iteration;
 //   * the boundary rows / columns of the RESIDUAL, neighbour to neighbour, once per iteration.  (The direction never
 //     crosses parts: the fused stencil launch recomputes it on its halo from the ghost copies of r and the old direction and
 //     keeps the result in its ghost rows and ghost columns.)
-// Transports:
-//   RCCL   one process per GPU.  The library owns its communicators (mi355cg_team_unique_id -> ncclCommInitRank); RCCL is
-//          resolved at run time from the librccl already in the process (torch's) or from the ROCm installation.
-//          The records: ncclAllGather issued on the COMPUTE stream, between producer and consumer launch (nothing else
-//          could run there: both launches of an iteration need all records).  The halo: one ncclSend/ncclRecv group per
-//          iteration on a SECOND stream and a second communicator, ordered with the compute stream by two events, so it
-//          travels while the update records are all-gathered.  The host never blocks inside an iteration.
-//   LOCAL  one process drives all parts, on one or several GPUs (one host thread per part when they are on different GPUs):
-//          records are written straight into every part's gathered buffer, halo segments are device-to-device copies.
+// Who drives the parts:
+//   RCCL   one process per GPU.  The library owns its communicator (mi355cg_team_unique_id -> ncclCommInitRank); RCCL is
+//          resolved at run time from the librccl already in the process (torch's) or from the ROCm installation.  At team
+//          creation the ranks exchange IPC handles through it and map each other's mailbox, residual vector and column buffer.
+//   LOCAL  one process drives all parts, on one or several GPUs (one host thread per part when they are on different GPUs).
 //          This is what a single-process host (the reference's DirichletSolver is one) uses, and what lets one GPU rehearse
 //          an 8-part run bit for bit.
+// How the records travel (mi355cg_team_s::rec_mode):
+//   MAILBOX  the last block of the producer launch stores the record, as 32 flagged 64-bit words, straight into the mailbox of
+//            every part (peer GPU memory over xGMI; IPC-mapped when the part is another process); the consumer launch polls its
+//            own mailbox in its prologue (bounded; WAIT_KERNEL) -- the hop costs one store latency and no launch, collective or
+//            event.  Ranks that share one physical GPU (rehearsals) let their STREAMS wait for an announcement word instead
+//            (hipStreamWaitValue64; WAIT_STREAM), because a polling kernel could keep the producing kernel off the CUs.
+//   RCCL     ncclAllGather of the flagged words on the COMPUTE stream, between producer and consumer launch.
+//   EVENTS   LOCAL teams whose parts share a GPU: direct stores + a hub stream joining the parts' events.
+// How the halo travels (halo_mode):
+//   PUSH         one small launch behind the update launch stores the boundary rows / packed columns into the neighbours' ghost
+//                rows / receive buffers; a stream-ordered 64-bit write (hipStreamWriteValue64) into each neighbour's mailbox
+//                announces them, and the neighbour's compute stream waits for that word before its next stencil launch.
+//   RCCL_INLINE  one ncclSend/ncclRecv group per iteration on the compute stream (one communicator, one stream: order-safe).
+//   RCCL_STREAM  the same group on a SECOND stream and communicator, ordered with the compute stream by two events.
+//   LOCAL        device-to-device copies on the parts' comm streams (one process).
 // Per iteration and part (default: ONE launch per phase; MI355CG_TEAM_SPLIT=1 cuts each phase into interior + edge launches
 // so that the halo travels beside the interior items instead):
-//     compute stream                                                       comm stream
-//     wait halo ; stencil -> record A (last block of the launch)
-//     all-gather A
-//     update -> record B ; pack columns ---------------------------------> halo exchange of r ; unpack columns
-//     all-gather B                                                        |
+//     wait halo ; stencil -> record A (last block of the launch) ............ every part's update launch needs all records A
+//     update -> record B ; pack columns ; halo of r ........................... every part's next stencil launch needs all records B
 // Sums travel as double-double pairs and are reduced in part order by every consumer, so every decomposition takes
-// bit-identical steps (tests/test_gpu_team.py).
+// bit-identical steps (tests/test_gpu_team.py, tests/test_gpu_team_ranks.py).
 #include <dlfcn.h>
+#include <unistd.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -118,9 +128,11 @@ std::vector<Seg> halo_segments(const GridParams& gp, const std::vector<Box>& bx)
 // ---- RCCL, resolved at run time -------------------------------------------------------------------------------------
 struct RcclApi {
     void* lib = nullptr;
+    std::string lib_name;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -129,23 +141,35 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
+// The copy already in the process first (PyTorch-ROCm bundles its own), then the ROCm installation's.  MI355CG_RCCL_LIB names
+// another library with the same eleven entry points instead (tests/nccl_shim: the host-staged stand-in that lets several rank
+// processes share ONE GPU, which RCCL itself refuses).
 RcclApi* rccl_api() {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.lib ? &api : nullptr;
-    tried = true;
-    // the copy already in the process first (PyTorch-ROCm bundles its own), then the ROCm installation's
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void* h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);
-    for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-    if (!h) return nullptr;
-#define MI355CG_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name)); if (!api.field) return nullptr
-    MI355CG_SYM(GetUniqueId, "ncclGetUniqueId"); MI355CG_SYM(CommInitRank, "ncclCommInitRank"); MI355CG_SYM(CommDestroy, "ncclCommDestroy");
-    MI355CG_SYM(AllGather, "ncclAllGather"); MI355CG_SYM(Send, "ncclSend"); MI355CG_SYM(Recv, "ncclRecv"); MI355CG_SYM(Broadcast, "ncclBroadcast");
-    MI355CG_SYM(GroupStart, "ncclGroupStart"); MI355CG_SYM(GroupEnd, "ncclGroupEnd"); MI355CG_SYM(GetErrorString, "ncclGetErrorString");
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        const char* over = getenv("MI355CG_RCCL_LIB");
+        if (over && *over) {
+            h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (h) api.lib_name = over;
+        } else {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);
+            if (h) api.lib_name = names[0];
+            for (int i = 0; !h && i < 3; ++i) { h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL); if (h) api.lib_name = names[i]; }
+        }
+        if (!h) return;
+        bool ok = true;
+#define MI355CG_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name)); if (!api.field) ok = false
+        MI355CG_SYM(GetUniqueId, "ncclGetUniqueId"); MI355CG_SYM(CommInitRank, "ncclCommInitRank"); MI355CG_SYM(CommDestroy, "ncclCommDestroy");
+        MI355CG_SYM(CommCount, "ncclCommCount");
+        MI355CG_SYM(AllGather, "ncclAllGather"); MI355CG_SYM(Send, "ncclSend"); MI355CG_SYM(Recv, "ncclRecv"); MI355CG_SYM(Broadcast, "ncclBroadcast");
+        MI355CG_SYM(GroupStart, "ncclGroupStart"); MI355CG_SYM(GroupEnd, "ncclGroupEnd"); MI355CG_SYM(GetErrorString, "ncclGetErrorString");
 #undef MI355CG_SYM
-    api.lib = h;
-    return &api;
+        if (ok) api.lib = h;
+    });
+    return api.lib ? &api : nullptr;
 }
 #define NCCLCK(expr)                                                                                          \
     do {                                                                                                      \
@@ -154,19 +178,35 @@ RcclApi* rccl_api() {
             return fail(MI355CG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl_api()->GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+// ---- mailboxes -------------------------------------------------------------------------------------------------------
+// One per part, in the part's own device memory (uncached allocation: peers write it while its kernels poll it), 64-bit words:
+//   rec[phase 0..1][slot 0..1][rank][kLLWords]   the parts' flagged records (cg_kernels.h); slot = iteration sequence number & 1
+//   flag[phase 0..1][rank]                       sequence number of the last record rank published (what a STREAM-level wait watches)
+//   halo[rank]                                   sequence number of the last halo rows / columns rank pushed into this part's ghost cells
+struct MboxLayout {
+    int W;
+    size_t rec(int ph, int slot, int rank) const { return ((size_t)(ph * 2 + slot) * W + rank) * kLLWords; }
+    size_t flag(int ph, int rank) const { return (size_t)4 * W * kLLWords + (size_t)ph * W + rank; }
+    size_t halo(int rank) const { return (size_t)4 * W * kLLWords + (size_t)2 * W + rank; }
+    size_t flags_begin() const { return (size_t)4 * W * kLLWords; }
+    size_t words() const { return (size_t)4 * W * kLLWords + (size_t)3 * W; }
+};
+// the 32-bit stamp of sequence number q: never 0 (a fresh mailbox holds zeros)
+inline unsigned stamp_of(u64 q) { return (unsigned)(q & 0x7fffffffu) | 0x80000000u; }
+
 // ---- small kernels of the team loop ------------------------------------------------------------------------------
 constexpr int kMaxLocalParts = kMaxRecDst;
-constexpr int kRecStop = kRecStopWord;
 struct TeamRecArgs {
     const double* part; int n, stride;
     int nsum, lo_off, max_first, nmax;            // as RecordArgs
     const int* stop_req;                          // pinned host word (update records only), may be null
-    double* dst[kMaxLocalParts]; int ndst;        // this part's slot in every local part's gathered buffer
+    RecSpec rs;                                   // destinations, slot, stamp
 };
+// the record of the initialisation pass (a launch of its own: k_init_fresh is a flat kernel without an arrival ticket)
 __global__ __launch_bounds__(kBlock) void k_team_record(const TeamRecArgs a) {
     __shared__ double lds[2 * kWaves];
-    __shared__ double rec[kRecHeader];
-    if (threadIdx.x < kRecHeader) rec[threadIdx.x] = 0.0;
+    __shared__ double rec[kRecWords];
+    if (threadIdx.x < kRecWords) rec[threadIdx.x] = 0.0;
     __syncthreads();
     for (int f = 0; f < a.nsum; ++f) {
         const dd t = reduce_parts_dd(a.part + f * a.stride, a.part + (f + a.lo_off) * a.stride, a.n, 1, lds);
@@ -176,21 +216,15 @@ __global__ __launch_bounds__(kBlock) void k_team_record(const TeamRecArgs a) {
         const double t = reduce_parts<true>(a.part + f * a.stride, a.n, 1, lds);
         if (threadIdx.x == 0) rec[f] = t;
     }
-    if (threadIdx.x == 0 && a.stop_req) rec[kRecStop] = *(const volatile int*)a.stop_req ? 1.0 : 0.0;
+    if (threadIdx.x == 0 && a.stop_req) rec[kRecStopWord] = *(const volatile int*)a.stop_req ? 1.0 : 0.0;
     __syncthreads();
-    for (int i = threadIdx.x; i < a.ndst * kRecHeader; i += kBlock) a.dst[i / kRecHeader][i % kRecHeader] = rec[i % kRecHeader];
+    publish_record(rec, a.rs);
 }
-// max over ranks of the stop word -> summary (after k_check wrote the rest of it)
-__global__ void k_team_stop(const double* gathered, int nranks, CgState* summary) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double m = 0.0;
-        for (int i = 0; i < nranks; ++i) m = fmax(m, gathered[i * kRecHeader + kRecStop]);
-        summary->pad_ = m > 0.0 ? 1 : 0;
-    }
-}
-// column messages: gather a vector's columns into the send buffer / scatter the receive buffer into ghost columns
+// halo messages <-> buffers: gather a vector's columns into the send buffer / scatter the receive buffer into ghost columns
+// (a column is strided in storage) and -- PUSH halo only -- into ghost rows (a row message lands in the receive buffer there,
+// because that, not the residual vector, is what the neighbour has mapped)
 constexpr int kMaxColSegs = 8;
-struct ColSeg { int x, y0, n; long long off; };
+struct ColSeg { int x, y0, n, row; long long off; };     // row = 0: cells (x, y0 .. y0+n-1); row = 1: cells (x .. x+n-1, y0)
 struct ColArgs { Geom g; double* v; double* buf; ColSeg s[kMaxColSegs]; int ns, scatter; };
 __global__ __launch_bounds__(kBlock) void k_cols(const ColArgs a) {
     for (int k = 0; k < a.ns; ++k) {
@@ -198,22 +232,57 @@ __global__ __launch_bounds__(kBlock) void k_cols(const ColArgs a) {
 #pragma unroll
         for (int j = 1; j < kMaxColSegs; ++j) if (j == k) s = a.s[j];
         for (int i = blockIdx.x * kBlock + threadIdx.x; i < s.n; i += gridDim.x * kBlock) {
-            double* cell = a.v + (row_off(a.g, s.y0 + i) - a.g.base0 + s.x);
+            double* cell = s.row ? a.v + (row_off(a.g, s.y0) - a.g.base0 + s.x + i) : a.v + (row_off(a.g, s.y0 + i) - a.g.base0 + s.x);
             if (a.scatter) *cell = a.buf[s.off + i]; else a.buf[s.off + i] = *cell;
         }
     }
 }
+// PUSH halo: this part's boundary rows / packed columns into the neighbours' receive buffers (their memory: a peer GPU's over
+// xGMI, mapped through IPC when the neighbour is another process).  Plain stores: the launch boundary publishes them, and the
+// stream-ordered flag write that follows tells the neighbour, whose stream then scatters them into its ghost cells.
+constexpr int kMaxPush = 8;
+struct PushSeg { const double* src; double* dst; int n; };
+struct PushArgs { PushSeg s[kMaxPush]; int ns; };
+__global__ __launch_bounds__(kBlock) void k_push(const PushArgs a) {
+    for (int k = 0; k < a.ns; ++k) {
+        PushSeg s = a.s[0];
+#pragma unroll
+        for (int j = 1; j < kMaxPush; ++j) if (j == k) s = a.s[j];
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < s.n; i += gridDim.x * kBlock) s.dst[i] = s.src[i];
+    }
+}
+
+enum { REC_EVENTS = 0, REC_RCCL = 1, REC_MAILBOX = 2 };                       // how a part's records reach the other parts
+enum { WAIT_KERNEL = 0, WAIT_STREAM = 1 };                                     // REC_MAILBOX: who waits for them
+enum { HALO_LOCAL = 0, HALO_RCCL_INLINE = 1, HALO_RCCL_STREAM = 2, HALO_PUSH = 3 };
+const char* rec_name(int m) { return m == REC_EVENTS ? "events" : m == REC_RCCL ? "rccl" : "mailbox"; }
+const char* wait_name(int m) { return m == WAIT_KERNEL ? "kernel" : "stream"; }
+const char* halo_name(int m) { return m == HALO_LOCAL ? "copies" : m == HALO_RCCL_INLINE ? "rccl-inline" : m == HALO_RCCL_STREAM ? "rccl-stream" : "push"; }
 
 struct TeamPart {
     mi355cg_ctx* c = nullptr;
     int rank = 0;
     hipStream_t comm = nullptr;
-    double *gA = nullptr, *gB = nullptr;                  // gathered records [world][kRecHeader]
-    double *send_cols = nullptr, *recv_cols = nullptr;    // packed column messages
-    double **dstA = nullptr, **dstB = nullptr;            // device arrays: where this part's records go (one slot per local part)
+    // What other parts write into lives in ONE slab of uncached memory from a per-process pool that is never handed back to HIP
+    // (IpcPool): [mailbox | receive buffer].  It is the only memory a rank exports through IPC.
+    void* slab = nullptr;
+    u64* mbox = nullptr;                                  // this part's mailbox (MboxLayout)
+    double* recv_cols = nullptr;                          // receive buffer: packed column messages, then (PUSH halo) the row messages
+    std::vector<u64*> peer_mbox;                          // [world]: part j's mailbox as this part's device addresses it (nullptr: not reachable)
+    std::vector<double*> peer_cols;                       // [world]: part j's receive buffer, same
+    std::vector<void*> ipc_opened;                        // mappings to close
+    double* send_cols = nullptr;                          // packed column messages to send
+    std::vector<long long> recv_row_off;                  // PUSH halo: where row message i of recvs lands in the receive buffer (-1: a column message)
+    ColArgs unpack_rows{};                                // PUSH halo: receive buffer -> ghost rows
+    u64 **dst_self[2] = {nullptr, nullptr};               // device arrays for RecSpec::dst, per phase: own mailbox only (REC_RCCL) ...
+    u64 **dst_all[2] = {nullptr, nullptr};                // ... or every reachable part's
+    u64 **flag_all[2] = {nullptr, nullptr};               // RecSpec::flag, matching dst_all
+    int ndst_all = 0;
     std::vector<Seg> sends, recvs;                        // ordered by (peer, id)
     std::vector<long long> send_off, recv_off;            // column messages: offset in send_cols / recv_cols
+    std::vector<int> halo_from, halo_to;                  // distinct neighbour ranks
     ColArgs pack{}, unpack{};
+    PushArgs push{};
     bool split = false;                                   // interior / edge launches (the part has neighbours)
     hipEvent_t ev_recA = nullptr, ev_gA = nullptr, ev_redge = nullptr, ev_recB = nullptr, ev_gB = nullptr, ev_halo = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> comm_pairs;     // profiling: event pairs on the comm stream
@@ -225,20 +294,27 @@ struct mi355cg_team_s {
     GridParams gp;
     int world = 1, decomp = 0;
     std::vector<Box> boxes;
+    std::vector<Geom> geoms;                // every part's storage geometry (a part addresses its neighbours' ghost rows with it)
     std::vector<Seg> segs;
     std::vector<TeamPart> parts;            // the parts this process drives (all of them: LOCAL; one: RCCL)
     bool rccl = false;
-    ncclComm_t comm = nullptr;              // records: ncclAllGather issued on the COMPUTE stream (no cross-stream hop on the critical path)
-    ncclComm_t comm_halo = nullptr;         // halo messages on the comm stream; its own communicator, so the two streams never serialise on one
-    hipStream_t hub = nullptr;              // LOCAL: joins the parts' record events
+    ncclComm_t comm = nullptr;              // records (REC_RCCL) and the halo of HALO_RCCL_INLINE: everything on the COMPUTE stream
+    ncclComm_t comm_halo = nullptr;         // HALO_RCCL_STREAM: the halo messages on the comm stream; its own communicator, so the two streams never serialise on one
+    int rccl_nranks = 0;                    // what ncclCommCount says
+    bool ipc_ok = false;                    // every rank could map every other rank's mailbox / residual / column buffer -- and reads ITS bytes through the mappings
+    std::string ipc_note = "-";             // why not, if not
+    bool shared_device = false;             // two ranks sit on the same physical GPU (rehearsals): kernels must not spin on each other
+    hipStream_t hub = nullptr;              // LOCAL, REC_EVENTS: joins the parts' record events
     hipEvent_t ev_hub = nullptr;
-    int* stop_h = nullptr;                  // pinned: this process's stop request, read by k_team_record
-    // Interior / edge launches per phase (the halo travels while the interior items run) or ONE launch per phase (the halo
-    // travels while the update records are all-gathered).  See team_solve; MI355CG_TEAM_SPLIT=1 selects the former.
+    hipStream_t side = nullptr;             // releases stream-level waits when a solve is abandoned
+    int* stop_h = nullptr;                  // pinned: this process's stop request, read by the update phase's record
+    u64 seq = 0;                            // iteration sequence number: stamps and slots of the records (identical on every rank)
+    int rec_mode = REC_EVENTS, wait_mode = WAIT_KERNEL, halo_mode = HALO_LOCAL;
+    u64 budget_ticks = 0;                   // what a kernel may wait for a record (100 MHz ticks)
+    double timeout_s = 30.0;
+    bool broken = false;                    // a solve was abandoned: the ranks' sequence numbers may differ, no further solves
+    // Interior / edge launches per phase (the halo travels while the interior items run) or ONE launch per phase.
     bool split_phases = false;
-    // RCCL: the halo group on the COMPUTE stream, between the update launch and the all-gather of its records (no second
-    // stream, no events), instead of on the comm stream beside them.  MI355CG_TEAM_HALO_INLINE.
-    bool halo_inline = false;
     bool profiling = false;
     double prof_kernel_ms = 0, prof_comm_ms = 0, prof_wall_ms = 0;     // per iteration, last profiled solve
     int hub_device = 0;
@@ -246,31 +322,110 @@ struct mi355cg_team_s {
 
 namespace {
 
+// Memory that other processes map (IPC) comes from a pool that never returns anything to HIP: an owner that frees exported memory
+// and allocates again has been seen to hand out a handle that a peer resolves to the OLD memory (and hipIpcGetMemHandle to refuse
+// recycled hipMalloc memory) once a process has created and destroyed a few teams.  A slab keeps its handle for the life of the process.
+struct IpcPool {
+    struct Slab { void* ptr; size_t bytes; int device; bool in_use; };
+    std::mutex mu;
+    std::vector<Slab> slabs;
+    int acquire(int device, size_t bytes, void** out) {
+        bytes = (bytes + 65535) / 65536 * 65536;
+        std::lock_guard<std::mutex> g(mu);
+        Slab* hit = nullptr;
+        for (auto& s : slabs) if (!s.in_use && s.device == device && s.bytes >= bytes && (!hit || s.bytes < hit->bytes)) hit = &s;
+        if (!hit) {
+            void* p = nullptr;
+            HIPCK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+            slabs.push_back(Slab{p, bytes, device, false});
+            hit = &slabs.back();
+        }
+        hit->in_use = true;
+        HIPCK(hipMemset(hit->ptr, 0, hit->bytes));
+        HIPCK(hipDeviceSynchronize());
+        *out = hit->ptr;
+        return MI355CG_OK;
+    }
+    void release(void* p) { std::lock_guard<std::mutex> g(mu); for (auto& s : slabs) if (s.ptr == p) s.in_use = false; }
+};
+IpcPool& ipc_pool() { static IpcPool pool; return pool; }
+inline size_t mbox_bytes(int world) { return (sizeof(u64) * MboxLayout{world}.words() + 255) / 256 * 256; }
+
+int boot_all_gather(mi355cg_team_s* t, const void* mine, void* all, size_t bytes);
 void team_free(mi355cg_team_s* t) {
     if (!t) return;
+    if (t->broken) return;                 // streams may never drain (a peer is gone): leak rather than hang in a synchronise
     for (auto& p : t->parts) {
         if (p.c) hipSetDevice(p.c->device);
         if (p.c && p.c->stream) hipStreamSynchronize(p.c->stream);
         if (p.comm) { hipStreamSynchronize(p.comm); }
     }
+    // IPC: every rank unmaps the other ranks' memory BEFORE any owner frees it (an owner that frees memory a peer still has mapped,
+    // then allocates again, has been seen to hand out a handle that the peer resolves to the OLD memory)
+    bool mapped = false;
+    for (auto& p : t->parts) {
+        if (p.c) hipSetDevice(p.c->device);
+        for (void* q : p.ipc_opened) if (q) { hipIpcCloseMemHandle(q); mapped = true; }
+        p.ipc_opened.clear();
+    }
+    (void)hipGetLastError();
+    if (t->rccl && t->comm && t->world > 1 && (mapped || t->ipc_ok) && rccl_api()) { int mine = 1; std::vector<int> all(t->world); (void)boot_all_gather(t, &mine, all.data(), sizeof(int)); }
     if (t->comm_halo && rccl_api()) rccl_api()->CommDestroy(t->comm_halo);
     if (t->comm && rccl_api()) rccl_api()->CommDestroy(t->comm);
     for (auto& p : t->parts) {
         if (p.c) hipSetDevice(p.c->device);
-        for (void* q : {(void*)p.gA, (void*)p.gB, (void*)p.send_cols, (void*)p.recv_cols, (void*)p.dstA, (void*)p.dstB}) if (q) hipFree(q);
+        if (p.slab) ipc_pool().release(p.slab);
+        for (void* q : {(void*)p.send_cols, (void*)p.dst_self[0], (void*)p.dst_self[1], (void*)p.dst_all[0], (void*)p.dst_all[1],
+                        (void*)p.flag_all[0], (void*)p.flag_all[1]}) if (q) hipFree(q);
         for (hipEvent_t e : {p.ev_recA, p.ev_gA, p.ev_redge, p.ev_recB, p.ev_gB, p.ev_halo}) if (e) hipEventDestroy(e);
         if (p.comm) hipStreamDestroy(p.comm);
         if (p.c) mi355cg_destroy(p.c);
     }
     if (t->hub) { hipSetDevice(t->hub_device); hipStreamDestroy(t->hub); }
+    if (t->side) hipStreamDestroy(t->side);
     if (t->ev_hub) hipEventDestroy(t->ev_hub);
     if (t->stop_h) hipHostFree(t->stop_h);
     delete t;
 }
 
-// Per-part resources and halo lists once the contexts exist.
+// The ordered message lists of one part and the layout of its buffers: every rank can compute them for every part.
+// Receive buffer: the column messages packed back to back (recv_off), then the row messages (recv_row_off; used by the PUSH halo).
+struct PartLists { std::vector<Seg> sends, recvs; std::vector<long long> send_off, recv_off, recv_row_off; long long send_len = 0, recv_len = 0, recv_total = 0; };
+PartLists part_lists(const std::vector<Seg>& segs, int rank) {
+    PartLists L;
+    for (auto& s : segs) { if (s.src == rank) L.sends.push_back(s); if (s.dst == rank) L.recvs.push_back(s); }
+    auto by_peer = [](bool send) { return [send](const Seg& a, const Seg& b) { const int pa = send ? a.dst : a.src, pb = send ? b.dst : b.src; return pa != pb ? pa < pb : a.id < b.id; }; };
+    std::sort(L.sends.begin(), L.sends.end(), by_peer(true));
+    std::sort(L.recvs.begin(), L.recvs.end(), by_peer(false));
+    for (auto& s : L.sends) { L.send_off.push_back(L.send_len); if (s.kind == 1) L.send_len += seg_count(s); }
+    for (auto& s : L.recvs) { L.recv_off.push_back(L.recv_len); if (s.kind == 1) L.recv_len += seg_count(s); }
+    L.recv_total = (L.recv_len + 31) / 32 * 32;                       // rows start 256-byte aligned
+    for (auto& s : L.recvs) { L.recv_row_off.push_back(s.kind == 0 ? L.recv_total : -1); if (s.kind == 0) L.recv_total += (seg_count(s) + 31) / 32 * 32; }
+    return L;
+}
+Geom part_geom(const GridParams& gp, const Box& bx) {
+    mi355cg_ctx c{};                                   // geometry only: no device is touched
+    c.gp = gp; c.dtype = MI355CG_F64; c.is_slab = true;
+    c.s_lo = bx.s_lo; c.s_hi = std::min(bx.s_hi, strips_total(gp, 2));
+    build_geom(&c, 2, bx.y_lo, bx.y_hi);
+    return c.g;
+}
+double* seg_ptr_g(const Geom& g, double* v, const Seg& s) { return v + (row_off(g, s.y0) - g.base0 + s.x0); }
+double* seg_ptr(const mi355cg_ctx* c, double* v, const Seg& s) { return seg_ptr_g(c->g, v, s); }
+
+int upload_ptrs(u64*** dev, const std::vector<u64*>& v) {
+    HIPCK(hipMalloc((void**)dev, sizeof(u64*) * std::max<size_t>(v.size(), 1)));
+    if (!v.empty()) HIPCK(hipMemcpy(*dev, v.data(), sizeof(u64*) * v.size(), hipMemcpyHostToDevice));
+    return MI355CG_OK;
+}
+
+// Per-part resources and halo lists once the contexts exist.  (The mailboxes of parts in other processes are mapped later:
+// team_map_peers.)
 int team_finish_setup(mi355cg_team_s* t) {
     t->segs = halo_segments(t->gp, t->boxes);
+    t->geoms.clear();
+    for (auto& b : t->boxes) t->geoms.push_back(part_geom(t->gp, b));
+    const MboxLayout ml{t->world};
     // Events that only order streams of ONE device need no system-scope fence (a default event writes back and invalidates the
     // caches when it fires: ~10 us on the compute stream between two launches).  Parts on several GPUs read each other's rows
     // after these events: those keep the default.
@@ -281,32 +436,31 @@ int team_finish_setup(mi355cg_team_s* t) {
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
         HIPCK(hipStreamCreateWithFlags(&p.comm, hipStreamNonBlocking));
-        if (int rc = alloc_vec(&p.gA, (long long)t->world * kRecHeader)) return rc;
-        if (int rc = alloc_vec(&p.gB, (long long)t->world * kRecHeader)) return rc;
+        const PartLists L = part_lists(t->segs, p.rank);
+        if (int rc = ipc_pool().acquire(c->device, mbox_bytes(t->world) + sizeof(double) * std::max<long long>(L.recv_total, 1), &p.slab)) return rc;
+        p.mbox = (u64*)p.slab;
+        p.recv_cols = (double*)((char*)p.slab + mbox_bytes(t->world));
+        (void)ml;
         for (hipEvent_t* e : {&p.ev_recA, &p.ev_gA, &p.ev_redge, &p.ev_recB, &p.ev_gB, &p.ev_halo}) HIPCK(hipEventCreateWithFlags(e, ev_flags));
-        for (auto& s : t->segs) { if (s.src == p.rank) p.sends.push_back(s); if (s.dst == p.rank) p.recvs.push_back(s); }
-        auto by_peer = [](bool send) { return [send](const Seg& a, const Seg& b) { const int pa = send ? a.dst : a.src, pb = send ? b.dst : b.src; return pa != pb ? pa < pb : a.id < b.id; }; };
-        std::sort(p.sends.begin(), p.sends.end(), by_peer(true));
-        std::sort(p.recvs.begin(), p.recvs.end(), by_peer(false));
+        p.sends = L.sends; p.recvs = L.recvs; p.send_off = L.send_off; p.recv_off = L.recv_off; p.recv_row_off = L.recv_row_off;
         p.split = !p.sends.empty() || !p.recvs.empty();
-        long long so = 0, ro = 0;
+        for (auto& s : p.sends) if (p.halo_to.empty() || p.halo_to.back() != s.dst) p.halo_to.push_back(s.dst);
+        for (auto& s : p.recvs) if (p.halo_from.empty() || p.halo_from.back() != s.src) p.halo_from.push_back(s.src);
         p.pack = ColArgs{}; p.unpack = ColArgs{};
         p.pack.g = c->g; p.unpack.g = c->g; p.unpack.scatter = 1;
-        for (auto& s : p.sends) { p.send_off.push_back(so); if (s.kind == 1) { if (p.pack.ns >= kMaxColSegs) return fail(MI355CG_ERR_INVALID, "too many column messages"); p.pack.s[p.pack.ns++] = ColSeg{s.x0, s.y0, (int)seg_count(s), so}; so += seg_count(s); } }
-        for (auto& s : p.recvs) { p.recv_off.push_back(ro); if (s.kind == 1) { if (p.unpack.ns >= kMaxColSegs) return fail(MI355CG_ERR_INVALID, "too many column messages"); p.unpack.s[p.unpack.ns++] = ColSeg{s.x0, s.y0, (int)seg_count(s), ro}; ro += seg_count(s); } }
-        if (int rc = alloc_vec(&p.send_cols, std::max<long long>(so, 1))) return rc;
-        if (int rc = alloc_vec(&p.recv_cols, std::max<long long>(ro, 1))) return rc;
-        p.pack.buf = p.send_cols; p.unpack.buf = p.recv_cols;
+        p.unpack_rows = ColArgs{}; p.unpack_rows.g = c->g; p.unpack_rows.scatter = 1;
+        for (size_t i = 0; i < p.sends.size(); ++i) if (p.sends[i].kind == 1) { if (p.pack.ns >= kMaxColSegs) return fail(MI355CG_ERR_INVALID, "too many column messages"); p.pack.s[p.pack.ns++] = ColSeg{p.sends[i].x0, p.sends[i].y0, (int)seg_count(p.sends[i]), 0, p.send_off[i]}; }
+        for (size_t i = 0; i < p.recvs.size(); ++i) {
+            const Seg& s = p.recvs[i];
+            ColArgs& u = s.kind == 1 ? p.unpack : p.unpack_rows;
+            if (u.ns >= kMaxColSegs) return fail(MI355CG_ERR_INVALID, "too many halo messages");
+            u.s[u.ns++] = s.kind == 1 ? ColSeg{s.x0, s.y0, (int)seg_count(s), 0, p.recv_off[i]} : ColSeg{s.x0, s.y0, (int)seg_count(s), 1, p.recv_row_off[i]};
+        }
+        if (int rc = alloc_vec(&p.send_cols, std::max<long long>(L.send_len, 1))) return rc;
+        p.pack.buf = p.send_cols; p.unpack.buf = p.recv_cols; p.unpack_rows.buf = p.recv_cols;
+        p.peer_mbox.assign(t->world, nullptr); p.peer_cols.assign(t->world, nullptr);
+        p.peer_mbox[p.rank] = p.mbox; p.peer_cols[p.rank] = p.recv_cols;
         HIPCK(hipDeviceSynchronize());
-    }
-    for (auto& p : t->parts) {                                     // every part's record goes to every local part's gathered buffer
-        HIPCK(hipSetDevice(p.c->device));
-        std::vector<double*> da, db;
-        for (auto& q : t->parts) { da.push_back(q.gA + (size_t)p.rank * kRecHeader); db.push_back(q.gB + (size_t)p.rank * kRecHeader); }
-        HIPCK(hipMalloc((void**)&p.dstA, sizeof(double*) * da.size()));
-        HIPCK(hipMalloc((void**)&p.dstB, sizeof(double*) * db.size()));
-        HIPCK(hipMemcpy(p.dstA, da.data(), sizeof(double*) * da.size(), hipMemcpyHostToDevice));
-        HIPCK(hipMemcpy(p.dstB, db.data(), sizeof(double*) * db.size(), hipMemcpyHostToDevice));
     }
     if (!t->rccl) {
         t->hub_device = t->parts[0].c->device;
@@ -323,24 +477,134 @@ int team_finish_setup(mi355cg_team_s* t) {
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCK(e);
             (void)hipGetLastError();
         }
+        for (auto& p : t->parts) for (auto& q : t->parts) { p.peer_mbox[q.rank] = q.mbox; p.peer_cols[q.rank] = q.recv_cols; }
     }
+    HIPCK(hipSetDevice(t->parts[0].c->device));
+    HIPCK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
     HIPCK(hipHostMalloc((void**)&t->stop_h, sizeof(int)));
     *t->stop_h = 0;
     return MI355CG_OK;
 }
 
-double* seg_ptr(const mi355cg_ctx* c, double* v, const Seg& s) { return v + (row_off(c->g, s.y0) - c->g.base0 + s.x0); }
+// The device-side destination tables of the records and the PUSH list, from peer_mbox / peer_cols.
+int team_build_tables(mi355cg_team_s* t) {
+    const MboxLayout ml{t->world};
+    for (auto& p : t->parts) {
+        HIPCK(hipSetDevice(p.c->device));
+        for (int ph = 0; ph < 2; ++ph) {
+            for (void* q : {(void*)p.dst_self[ph], (void*)p.dst_all[ph], (void*)p.flag_all[ph]}) if (q) hipFree(q);
+            p.dst_self[ph] = p.dst_all[ph] = p.flag_all[ph] = nullptr;
+            std::vector<u64*> self{p.mbox + ml.rec(ph, 0, p.rank)}, all, flags;
+            for (int j = 0; j < t->world; ++j) if (p.peer_mbox[j]) { all.push_back(p.peer_mbox[j] + ml.rec(ph, 0, p.rank)); flags.push_back(p.peer_mbox[j] + ml.flag(ph, p.rank)); }
+            if (int rc = upload_ptrs(&p.dst_self[ph], self)) return rc;
+            if (int rc = upload_ptrs(&p.dst_all[ph], all)) return rc;
+            if (int rc = upload_ptrs(&p.flag_all[ph], flags)) return rc;
+            p.ndst_all = (int)all.size();
+        }
+        // PUSH: every outgoing message as (source in this part, destination in the neighbour's memory)
+        p.push = PushArgs{};
+        bool reach = true;
+        for (size_t i = 0; i < p.sends.size(); ++i) {
+            const Seg& s = p.sends[i];
+            if (!p.peer_cols[s.dst]) { reach = false; break; }
+            if (p.push.ns >= kMaxPush) return fail(MI355CG_ERR_INVALID, "too many halo messages for one push launch");
+            PushSeg ps{};
+            ps.n = (int)seg_count(s);
+            const PartLists Lq = part_lists(t->segs, s.dst);               // where the receiver expects this message in ITS receive buffer
+            long long off = -1;
+            for (size_t j = 0; j < Lq.recvs.size(); ++j) if (Lq.recvs[j].id == s.id) off = s.kind == 0 ? Lq.recv_row_off[j] : Lq.recv_off[j];
+            if (off < 0) return fail(MI355CG_ERR_STATE, "halo message %d has no receiver", s.id);
+            ps.src = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.send_cols + p.send_off[i];
+            ps.dst = p.peer_cols[s.dst] + off;
+            p.push.s[p.push.ns++] = ps;
+        }
+        if (!reach) p.push.ns = -1;
+    }
+    return MI355CG_OK;
+}
 
-// all-gather of the records of phase `which` (0 = A, 1 = B): after it every part's compute stream may read its gathered buffer
-int team_exchange_records(mi355cg_team_s* t, int which) {
-    if (t->rccl) {
-        // in-stream: the compute stream itself carries the all-gather between the record kernel and the consumer launch
+// ---- waiting without hanging -------------------------------------------------------------------------------------------
+// Every wait of the host on a team stream is bounded: a stream that does not drain within the team's timeout is taken to be
+// stuck behind a peer that will never deliver, its stream-level waits are released (all-ones into the flag words, so the kernels
+// behind them run, miss their records within their own budget and end the solve), and the solve returns MI355CG_ERR_STATE.
+int bounded_sync(mi355cg_team_s* t, hipStream_t st, const volatile int* stop_flag, double seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (stop_flag && *stop_flag) *t->stop_h = 1;
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return MI355CG_OK;
+        if (q != hipErrorNotReady) HIPCK(q);
+        if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return -1;
+        if (stop_flag) std::this_thread::yield(); else if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+int team_abandon(mi355cg_team_s* t, const char* what) {
+    t->broken = true;
+    const MboxLayout ml{t->world};
+    for (auto& p : t->parts) {
+        hipSetDevice(p.c->device);
+        hipMemsetAsync(p.mbox + ml.flags_begin(), 0xff, sizeof(u64) * (ml.words() - ml.flags_begin()), t->side);
+    }
+    hipStreamSynchronize(t->side);
+    for (auto& p : t->parts) { hipSetDevice(p.c->device); bounded_sync(t, p.c->stream, nullptr, 5.0 + 2e-8 * (double)t->budget_ticks); }
+    (void)hipGetLastError();
+    return fail(MI355CG_ERR_STATE, "team solve abandoned: %s (no progress within %.0f s; a peer did not deliver).  The team cannot be used again", what, t->timeout_s);
+}
+
+// ---- records ---------------------------------------------------------------------------------------------------------
+// the record a producer launch writes itself when it ends a phase (cg_kernels.h: arrive_and_record)
+RecSpec team_rec_spec(mi355cg_team_s* t, TeamPart& p, int which, int nslots, u64 seq) {
+    const MboxLayout ml{t->world};
+    RecSpec rs{};
+    rs.enabled = 1; rs.nslots = nslots; rs.ticket = p.c->ticket; rs.stop_req = which == 1 ? t->stop_h : nullptr;
+    const bool everywhere = t->rec_mode != REC_RCCL;
+    rs.ndst = everywhere ? p.ndst_all : 1;
+    rs.dst = everywhere ? p.dst_all[which] : p.dst_self[which];
+    rs.flag = (everywhere && t->rec_mode == REC_MAILBOX && t->wait_mode == WAIT_STREAM) ? p.flag_all[which] : nullptr;
+    rs.slot_words = (int)(ml.rec(0, 1, 0) - ml.rec(0, 0, 0));
+    rs.seq = stamp_of(seq); rs.slot = (int)(seq & 1); rs.flag_value = seq;
+    return rs;
+}
+// the same record from a separate one-block launch (after the initialisation pass)
+void team_record(mi355cg_team_s* t, TeamPart& p, int which, int nslots, u64 seq) {
+    mi355cg_ctx* c = p.c;
+    TeamRecArgs a{};
+    if (which == 0) { a.part = c->partA; a.stride = c->strideA; a.nsum = kNumSumsA; a.lo_off = FA_LO; a.max_first = 0; a.nmax = 0; }
+    else { a.part = c->partB; a.stride = c->strideB; a.nsum = kNumSumsB; a.lo_off = FB_LO; a.max_first = FB_RMAX; a.nmax = 3; }
+    a.stop_req = nullptr;        // the record of the initialisation pass never carries a stop request: the first one that can is iteration 1's
+    a.n = nslots;
+    a.rs = team_rec_spec(t, p, which, nslots, seq);
+    hipLaunchKernelGGL(k_team_record, dim3(1), dim3(kBlock), 0, c->stream, a);
+    if (t->rec_mode == REC_EVENTS) hipEventRecord(which == 0 ? p.ev_recA : p.ev_recB, c->stream);
+}
+// where a consumer launch of part p finds the records of phase `which` with sequence number seq
+PartSrc team_gsrc(const mi355cg_team_s* t, TeamPart& p, int which, u64 seq) {
+    const MboxLayout ml{t->world};
+    PartSrc s{};
+    s.rec.mbox = p.mbox + ml.rec(which, (int)(seq & 1), 0); s.rec.world = t->world; s.rec.stamp = stamp_of(seq); s.rec.budget = t->budget_ticks;
+    return s;
+}
+// REC_MAILBOX + WAIT_STREAM: the compute stream itself waits until every part's record of (which, seq) has been announced
+int part_wait_records(mi355cg_team_s* t, TeamPart& p, int which, u64 seq) {
+    if (t->rec_mode != REC_MAILBOX || t->wait_mode != WAIT_STREAM) return MI355CG_OK;
+    const MboxLayout ml{t->world};
+    for (int j = 0; j < t->world; ++j) HIPCK(hipStreamWaitValue64(p.c->stream, p.mbox + ml.flag(which, j), seq, hipStreamWaitValueGte, ~0ull));
+    return MI355CG_OK;
+}
+
+// after the producers of phase `which` (0 = A, 1 = B) have been enqueued: whatever the transport needs so that every part's
+// compute stream may run the consumer launch
+int team_exchange_records(mi355cg_team_s* t, int which, u64 seq) {
+    if (t->rec_mode == REC_MAILBOX) return MI355CG_OK;                 // the producers' last blocks deliver; the consumers poll (or their streams wait)
+    if (t->rec_mode == REC_RCCL) {
+        // in-stream: the compute stream itself carries the all-gather between the producer and the consumer launch
         TeamPart& p = t->parts[0];
-        double* g = which == 0 ? p.gA : p.gB;
+        const MboxLayout ml{t->world};
+        u64* g = p.mbox + ml.rec(which, (int)(seq & 1), 0);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.c->stream); }
         if (t->world > 1 || env_int("MI355CG_FORCE_COLLECTIVES", 0))
-            NCCLCK(rccl_api()->AllGather(g + (size_t)p.rank * kRecHeader, g, kRecHeader, ncclDouble, t->comm, p.c->stream));     // in place
+            NCCLCK(rccl_api()->AllGather(g + (size_t)p.rank * kLLWords, g, kLLWords, ncclUint64, t->comm, p.c->stream));     // in place
         if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.c->stream); p.comm_pairs.push_back({e0, e1}); } }
         return MI355CG_OK;
     }
@@ -351,107 +615,134 @@ int team_exchange_records(mi355cg_team_s* t, int which) {
     return MI355CG_OK;
 }
 
+// ---- halo ------------------------------------------------------------------------------------------------------------
 int part_halo_in(mi355cg_team_s* t, TeamPart& p);
-// boundary rows / columns of r to the neighbours; ev_halo of every part fires when its ghost cells are in place
-int team_exchange_halo(mi355cg_team_s* t) {
+// RCCL: this rank's messages of one exchange as ONE group on stream hs.  An error inside the group still closes it.
+int rccl_halo_group(mi355cg_team_s* t, TeamPart& p, ncclComm_t comm, hipStream_t hs) {
+    RcclApi* api = rccl_api();
+    NCCLCK(api->GroupStart());
+    ncclResult_t first = ncclSuccess;
+    for (size_t i = 0; i < p.sends.size() && first == ncclSuccess; ++i) {
+        const Seg& s = p.sends[i];
+        const double* src = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.send_cols + p.send_off[i];
+        first = api->Send(src, (size_t)seg_count(s), ncclDouble, s.dst, comm, hs);
+    }
+    for (size_t i = 0; i < p.recvs.size() && first == ncclSuccess; ++i) {
+        const Seg& s = p.recvs[i];
+        double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
+        first = api->Recv(dst, (size_t)seg_count(s), ncclDouble, s.src, comm, hs);
+    }
+    const ncclResult_t end = api->GroupEnd();
+    if (first != ncclSuccess) return fail(MI355CG_ERR_HIP, "ncclSend/ncclRecv failed: %s", api->GetErrorString(first));
+    NCCLCK(end);
+    return MI355CG_OK;
+}
+// After the update launches (and the column packs) of iteration `seq` have been enqueued: get every part's boundary rows /
+// columns of r into its neighbours' ghost cells.  ev_halo (LOCAL, RCCL_STREAM) fires when a part's ghost cells are in place.
+int team_exchange_halo(mi355cg_team_s* t, u64 seq) {
+    if (t->halo_mode == HALO_PUSH) return MI355CG_OK;                  // part_push_halo, right behind the update launch
     if (t->rccl) {
         TeamPart& p = t->parts[0];
-        const hipStream_t hs = t->halo_inline ? p.c->stream : p.comm;
-        if (!t->halo_inline) HIPCK(hipStreamWaitEvent(p.comm, p.ev_redge, 0));
+        const bool inl = t->halo_mode == HALO_RCCL_INLINE;
+        const hipStream_t hs = inl ? p.c->stream : p.comm;
+        if (!inl) HIPCK(hipStreamWaitEvent(p.comm, p.ev_redge, 0));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, hs); }
         if (!p.sends.empty() || !p.recvs.empty()) {
-            NCCLCK(rccl_api()->GroupStart());
-            for (size_t i = 0; i < p.sends.size(); ++i) {
-                const Seg& s = p.sends[i];
-                const double* src = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.send_cols + p.send_off[i];
-                NCCLCK(rccl_api()->Send(src, (size_t)seg_count(s), ncclDouble, s.dst, t->comm_halo, hs));
-            }
-            for (size_t i = 0; i < p.recvs.size(); ++i) {
-                const Seg& s = p.recvs[i];
-                double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
-                NCCLCK(rccl_api()->Recv(dst, (size_t)seg_count(s), ncclDouble, s.src, t->comm_halo, hs));
-            }
-            NCCLCK(rccl_api()->GroupEnd());
+            if (int rc = rccl_halo_group(t, p, inl ? t->comm : t->comm_halo, hs)) return rc;
             if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, hs, a); }
         }
         if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, hs); p.comm_pairs.push_back({e0, e1}); } }
-        if (!t->halo_inline) HIPCK(hipEventRecord(p.ev_halo, p.comm));
+        if (!inl) HIPCK(hipEventRecord(p.ev_halo, p.comm));
         HIPCK(hipGetLastError());
         return MI355CG_OK;
     }
     for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_halo_in(t, p)) return rc; }      // p = destination
     return MI355CG_OK;
 }
-
-// the record a producer launch writes itself when it ends a phase (cg_kernels.h: arrive_and_record)
-RecSpec team_rec_spec(mi355cg_team_s* t, TeamPart& p, int which, int nslots) {
-    RecSpec rs{};
-    rs.enabled = 1; rs.nslots = nslots; rs.ticket = p.c->ticket; rs.stop_req = which == 1 ? t->stop_h : nullptr;
-    rs.ndst = (int)t->parts.size(); rs.dst = which == 0 ? p.dstA : p.dstB;
-    return rs;
+// HALO_PUSH, producer side: one launch stores this part's boundary cells into the neighbours' memory; the stream then tells each
+// neighbour (a stream-ordered 64-bit write into its mailbox: it executes after the launch has completed and published its stores)
+int part_push_halo(mi355cg_team_s* t, TeamPart& p, u64 seq) {
+    if (t->halo_mode != HALO_PUSH || p.sends.empty()) return MI355CG_OK;
+    const MboxLayout ml{t->world};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.c->stream); }
+    hipLaunchKernelGGL(k_push, dim3(32), dim3(kBlock), 0, p.c->stream, p.push);
+    for (int j : p.halo_to) HIPCK(hipStreamWriteValue64(p.c->stream, p.peer_mbox[j] + ml.halo(p.rank), seq, 0));
+    if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.c->stream); p.comm_pairs.push_back({e0, e1}); } }
+    return MI355CG_OK;
 }
-
-// the same record from a separate one-block launch (after the initialisation pass)
-void team_record(mi355cg_team_s* t, TeamPart& p, int which, int nslots) {
-    mi355cg_ctx* c = p.c;
-    TeamRecArgs a{};
-    if (which == 0) { a.part = c->partA; a.stride = c->strideA; a.nsum = kNumSumsA; a.lo_off = FA_LO; a.max_first = 0; a.nmax = 0; }
-    else { a.part = c->partB; a.stride = c->strideB; a.nsum = kNumSumsB; a.lo_off = FB_LO; a.max_first = FB_RMAX; a.nmax = 3; a.stop_req = t->stop_h; }
-    a.n = nslots;
-    a.ndst = 0;
-    for (auto& q : t->parts) a.dst[a.ndst++] = (which == 0 ? q.gA : q.gB) + (size_t)p.rank * kRecHeader;
-    hipLaunchKernelGGL(k_team_record, dim3(1), dim3(kBlock), 0, c->stream, a);
-    if (!t->rccl) hipEventRecord(which == 0 ? p.ev_recA : p.ev_recB, c->stream);
+// HALO_PUSH, consumer side: the compute stream waits for the neighbours' announcements of iteration `seq`, then scatters the columns
+int part_wait_halo(mi355cg_team_s* t, TeamPart& p, u64 seq) {
+    if (t->halo_mode != HALO_PUSH || p.recvs.empty()) return MI355CG_OK;
+    const MboxLayout ml{t->world};
+    for (int j : p.halo_from) HIPCK(hipStreamWaitValue64(p.c->stream, p.mbox + ml.halo(j), seq, hipStreamWaitValueGte, ~0ull));
+    // one launch scatters everything that arrived: row messages into the ghost rows, column messages into the ghost columns
+    ColArgs a = p.unpack_rows; a.v = p.c->r;
+    for (int k = 0; k < p.unpack.ns && a.ns < kMaxColSegs; ++k) a.s[a.ns++] = p.unpack.s[k];
+    if (a.ns < p.unpack_rows.ns + p.unpack.ns) return fail(MI355CG_ERR_INVALID, "too many halo messages for one scatter launch");
+    if (a.ns) hipLaunchKernelGGL(k_cols, dim3(32), dim3(kBlock), 0, p.c->stream, a);
+    return MI355CG_OK;
 }
-
-PartSrc team_gsrc(const mi355cg_team_s* t, TeamPart& p, int which) { return PartSrc{which == 0 ? p.gA : p.gB, t->world, 1, kRecHeader}; }
+bool halo_uses_events(const mi355cg_team_s* t) { return t->halo_mode == HALO_LOCAL || t->halo_mode == HALO_RCCL_STREAM; }
 
 // ---- one part's share of an iteration (called by the one driving thread, or by the part's own thread) --------------
-// stencil phase: the launch that ends it writes the part's record (its last block)
-int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
+// stencil phase of iteration seq: consumes the update records of seq - 1 (seqB) and the halo of r that followed them; the launch
+// that ends it writes the part's record (its last block)
+int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 seqB, u64 seq) {
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
-    if (p.split && !t->split_phases && !t->halo_inline) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));      // one launch: the halo has to be there first
+    const bool ev = halo_uses_events(t);
+    if (int rc = part_wait_records(t, p, 1, seqB)) return rc;
+    if (p.split && !t->split_phases) {                                  // one launch: the halo has to be there first
+        if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
+        if (int rc = part_wait_halo(t, p, seqB)) return rc;
+    }
     prof_begin(c, &e0);
     if (p.split && t->split_phases) {
-        const RecSpec rs = team_rec_spec(t, p, 0, c->interior.grid + c->edge.grid);
-        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 1));
+        const RecSpec rs = team_rec_spec(t, p, 0, c->interior.grid + c->edge.grid, seq);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 1, seqB));
         prof_end(c, 0, e0);
-        HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
+        if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
+        if (int rc = part_wait_halo(t, p, seqB)) return rc;
         prof_begin(c, &e0);
-        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 1), &rs);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 1, seqB), &rs);
     } else {
-        const RecSpec rs = team_rec_spec(t, p, 0, c->whole.grid);
-        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), team_gsrc(t, p, 1), &rs);
+        const RecSpec rs = team_rec_spec(t, p, 0, c->whole.grid, seq);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), team_gsrc(t, p, 1, seqB), &rs);
     }
     prof_end(c, 0, e0);
     c->cur = (c->cur + 1) % c->xsteps;
-    if (!t->rccl) HIPCK(hipEventRecord(p.ev_recA, c->stream));
+    if (t->rec_mode == REC_EVENTS) HIPCK(hipEventRecord(p.ev_recA, c->stream));
     return MI355CG_OK;
 }
-// update phase: edge items first, so the halo of r is on its way while the interior is updated
-int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
+// update phase: edge items first (split), so the halo of r is on its way while the interior is updated
+int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 seq) {
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
+    const bool ev = halo_uses_events(t);
+    if (int rc = part_wait_records(t, p, 0, seq)) return rc;
     prof_begin(c, &e0);
     if (p.split && t->split_phases) {
-        const RecSpec rs = team_rec_spec(t, p, 1, c->interior.grid + c->edge.grid);
+        const RecSpec rs = team_rec_spec(t, p, 1, c->interior.grid + c->edge.grid, seq);
         const bool has_int = c->interior.wl.nitems > 0;
-        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 0), has_int ? nullptr : &rs);
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 0, seq), has_int ? nullptr : &rs);
         if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
         prof_end(c, 1, e0);
-        HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        if (ev) HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        if (int rc = part_push_halo(t, p, seq)) return rc;
         prof_begin(c, &e0);
-        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 0), &rs);
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 0, seq), &rs);
+        prof_end(c, 1, e0);
     } else {
-        const RecSpec rs = team_rec_spec(t, p, 1, c->whole.grid);
-        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0), &rs);
+        const RecSpec rs = team_rec_spec(t, p, 1, c->whole.grid, seq);
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0, seq), &rs);
         if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
-        if (!t->halo_inline) HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        prof_end(c, 1, e0);
+        if (ev) HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        if (int rc = part_push_halo(t, p, seq)) return rc;
     }
-    prof_end(c, 1, e0);
-    if (!t->rccl) HIPCK(hipEventRecord(p.ev_recB, c->stream));
+    if (t->rec_mode == REC_EVENTS) HIPCK(hipEventRecord(p.ev_recB, c->stream));
     HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
@@ -476,17 +767,17 @@ int part_halo_in(mi355cg_team_s* t, TeamPart& p) {
     return MI355CG_OK;
 }
 // the decision of the last iteration, for the host (every part evaluates it: all parts hold the same records)
-int part_poll_enqueue(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg) {
-    launch_check(p.c, cfg, p.c->stream, team_gsrc(t, p, 1));
-    hipLaunchKernelGGL(k_team_stop, dim3(1), dim3(64), 0, p.c->stream, p.gB, t->world, p.c->summary);
+int part_poll_enqueue(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 seqB) {
+    if (int rc = part_wait_records(t, p, 1, seqB)) return rc;
+    launch_check(p.c, cfg, p.c->stream, team_gsrc(t, p, 1, seqB));
     return MI355CG_OK;
 }
 
 // ---- LOCAL transport with one host thread per part -------------------------------------------------------------------
 // One thread issues ~20 runtime calls per part and iteration; with the parts on 8 different GPUs that is the host, not the GPUs,
-// setting the pace.  Here every part has its own thread; the threads meet at two barriers per
-// iteration, each right after the events the other parts are about to wait on have been recorded (an event has to be
-// RECORDED before another thread may enqueue a wait on it).  Everything between the barriers is the part's own stream work.
+// setting the pace.  Here every part has its own thread; the threads meet at barriers inside an iteration, each right after the
+// events the other parts are about to wait on have been recorded (an event has to be RECORDED before another thread may enqueue
+// a wait on it).  With the records in mailboxes (REC_MAILBOX) only the halo events are left: one barrier per iteration.
 struct TeamCrew {
     mi355cg_team_s* t = nullptr;
     IterCfg cfg{};
@@ -497,10 +788,11 @@ struct TeamCrew {
     std::mutex mu;                       // chunk hand-over (workers sleep between chunks: the host waits for the device there)
     std::condition_variable cv;
     int chunk_seq = 0, chunk_m = 0, done_count = 0;
+    u64 chunk_seq0 = 0;
     bool chunk_poll = false, quit = false;
 
     void note_error(int rc) { int zero = 0; if (error.compare_exchange_strong(zero, rc)) { std::lock_guard<std::mutex> g(mu); error_text = g_err; } }
-    // spinning barrier for the two meeting points inside an iteration (microseconds apart); gives way when there are more
+    // spinning barrier for the meeting points inside an iteration (microseconds apart); gives way when there are more
     // threads than cores; returns false once any thread has failed
     bool barrier() {
         const int gen = generation.load(std::memory_order_acquire);
@@ -516,62 +808,115 @@ struct TeamCrew {
         }
         return error.load(std::memory_order_relaxed) == 0;
     }
-    // the iterations of one chunk as seen by part i
-    int run_chunk(int i, int m, bool poll) {
+    // the iterations of one chunk as seen by part i; seq0 = sequence number of the last update records before the chunk
+    int run_chunk(int i, int m, bool poll, u64 seq0) {
         TeamPart& p = t->parts[i];
+        const bool ev_rec = t->rec_mode == REC_EVENTS;
+        u64 seqB = seq0;
         for (int k = 0; k < m; ++k) {
-            if (int rc = part_stencil_phase(t, p, cfg)) return rc;
+            const u64 seq = seqB + 1;
+            if (int rc = part_stencil_phase(t, p, cfg, seqB, seq)) return rc;
+            if (ev_rec) {
+                if (!barrier()) return MI355CG_ERR_STATE;
+                for (auto& q : t->parts) if (&q != &p) HIPCK(hipStreamWaitEvent(p.c->stream, q.ev_recA, 0));
+            }
+            if (int rc = part_update_phase(t, p, cfg, seq)) return rc;
             if (!barrier()) return MI355CG_ERR_STATE;
-            for (auto& q : t->parts) if (&q != &p) HIPCK(hipStreamWaitEvent(p.c->stream, q.ev_recA, 0));
-            if (int rc = part_update_phase(t, p, cfg)) return rc;
-            if (!barrier()) return MI355CG_ERR_STATE;
-            if (int rc = part_halo_in(t, p)) return rc;
-            for (auto& q : t->parts) if (&q != &p) HIPCK(hipStreamWaitEvent(p.c->stream, q.ev_recB, 0));
+            if (t->halo_mode == HALO_LOCAL) if (int rc = part_halo_in(t, p)) return rc;
+            if (ev_rec) for (auto& q : t->parts) if (&q != &p) HIPCK(hipStreamWaitEvent(p.c->stream, q.ev_recB, 0));
+            seqB = seq;
         }
-        if (poll) if (int rc = part_poll_enqueue(t, p, cfg)) return rc;
+        if (poll) if (int rc = part_poll_enqueue(t, p, cfg, seqB)) return rc;
         return MI355CG_OK;
     }
     void worker(int i) {
         if (hipSetDevice(t->parts[i].c->device) != hipSuccess) { fail(MI355CG_ERR_HIP, "hipSetDevice failed in a team thread"); note_error(MI355CG_ERR_HIP); }
         int seen = 0;
         for (;;) {
-            int m; bool poll;
+            int m; bool poll; u64 seq0;
             {
                 std::unique_lock<std::mutex> g(mu);
                 cv.wait(g, [&] { return quit || chunk_seq != seen; });
                 if (quit) return;
-                seen = chunk_seq; m = chunk_m; poll = chunk_poll;
+                seen = chunk_seq; m = chunk_m; poll = chunk_poll; seq0 = chunk_seq0;
             }
-            if (!error.load()) if (int rc = run_chunk(i, m, poll)) { if (rc != MI355CG_ERR_STATE || !error.load()) note_error(rc); }
+            if (!error.load()) if (int rc = run_chunk(i, m, poll, seq0)) { if (rc != MI355CG_ERR_STATE || !error.load()) note_error(rc); }
             { std::lock_guard<std::mutex> g(mu); ++done_count; }
             cv.notify_all();
         }
     }
     // called by the solving thread (which is part 0's thread): run m iterations on every part, return when all are enqueued
-    int chunk(int m, bool poll) {
-        { std::lock_guard<std::mutex> g(mu); chunk_m = m; chunk_poll = poll; done_count = 0; ++chunk_seq; }
+    int chunk(int m, bool poll, u64 seq0) {
+        { std::lock_guard<std::mutex> g(mu); chunk_m = m; chunk_poll = poll; chunk_seq0 = seq0; done_count = 0; ++chunk_seq; }
         cv.notify_all();
         if (hipSetDevice(t->parts[0].c->device) != hipSuccess) { fail(MI355CG_ERR_HIP, "hipSetDevice failed"); note_error(MI355CG_ERR_HIP); }
-        if (!error.load()) if (int rc = run_chunk(0, m, poll)) { if (rc != MI355CG_ERR_STATE || !error.load()) note_error(rc); }
+        if (!error.load()) if (int rc = run_chunk(0, m, poll, seq0)) { if (rc != MI355CG_ERR_STATE || !error.load()) note_error(rc); }
         { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return done_count == nthreads - 1; }); }
         if (const int rc = error.load()) { g_err = error_text; return rc; }
         return MI355CG_OK;
     }
 };
 
+int env_choice(const char* name, std::initializer_list<const char*> names, int dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    int k = 0;
+    for (const char* n : names) { if (strcmp(v, n) == 0) return k; ++k; }
+    return dflt;
+}
+
+// How this solve moves records and halos (every rank reads the same environment and holds the same ipc_ok / shared_device):
+//   MI355CG_TEAM_RECORDS = auto | rccl | mailbox | events      MI355CG_TEAM_WAIT = auto | kernel | stream
+//   MI355CG_TEAM_HALO    = auto | inline | stream | push       MI355CG_TEAM_TIMEOUT_MS
+int team_pick_modes(mi355cg_team_s* t) {
+    bool several_devices = false;
+    for (auto& p : t->parts) if (p.c->device != t->parts[0].c->device) several_devices = true;
+    const int rec_env = env_choice("MI355CG_TEAM_RECORDS", {"auto", "rccl", "mailbox", "events"}, 0);
+    const int wait_env = env_choice("MI355CG_TEAM_WAIT", {"auto", "kernel", "stream"}, 0);
+    int halo_env = env_choice("MI355CG_TEAM_HALO", {"auto", "inline", "stream", "push"}, 0);
+    if (halo_env == 0 && env_int("MI355CG_TEAM_HALO_INLINE", 0)) halo_env = 1;
+    t->split_phases = env_int("MI355CG_TEAM_SPLIT", 0) != 0;
+    t->timeout_s = std::max(1, env_int("MI355CG_TEAM_TIMEOUT_MS", 30000)) * 1e-3;
+    t->budget_ticks = (u64)(t->timeout_s * 1e8);
+    if (t->rccl) {
+        const bool solo = t->world == 1;
+        t->rec_mode = rec_env == 1 ? REC_RCCL : rec_env == 2 ? REC_MAILBOX : ((t->ipc_ok || solo) ? REC_MAILBOX : REC_RCCL);
+        if (rec_env == 3) return fail(MI355CG_ERR_INVALID, "MI355CG_TEAM_RECORDS=events is for one-process teams");
+        if (t->rec_mode == REC_MAILBOX && !(t->ipc_ok || solo)) return fail(MI355CG_ERR_STATE, "MI355CG_TEAM_RECORDS=mailbox: the ranks could not map each other's mailboxes (IPC)");
+        // kernels of ranks that share one physical GPU must not spin on each other (the waiting one may keep the producing one off the CUs)
+        t->wait_mode = wait_env == 1 ? WAIT_KERNEL : wait_env == 2 ? WAIT_STREAM : (t->shared_device ? WAIT_STREAM : WAIT_KERNEL);
+        t->halo_mode = halo_env == 1 ? HALO_RCCL_INLINE : halo_env == 2 ? HALO_RCCL_STREAM : halo_env == 3 ? HALO_PUSH : ((t->ipc_ok || solo) ? HALO_PUSH : HALO_RCCL_INLINE);
+        if (t->halo_mode == HALO_PUSH && !(t->ipc_ok || solo)) return fail(MI355CG_ERR_STATE, "MI355CG_TEAM_HALO=push: the ranks could not map each other's vectors (IPC)");
+        if (t->halo_mode == HALO_RCCL_STREAM && !solo && !t->comm_halo) return fail(MI355CG_ERR_STATE, "MI355CG_TEAM_HALO=stream needs the second communicator (create the team with MI355CG_TEAM_HALO=stream set)");
+        if (t->split_phases && t->halo_mode == HALO_RCCL_INLINE) t->split_phases = false;      // nothing to overlap with
+    } else {
+        // one process: parts that share a GPU order their streams with events (a kernel that polls would keep the producer off the
+        // CUs); parts on GPUs of their own poll their mailboxes -- no hub stream, no event joins on the critical path
+        if (rec_env == 1) return fail(MI355CG_ERR_INVALID, "MI355CG_TEAM_RECORDS=rccl is for one-process-per-GPU teams");
+        const bool distinct = t->parts.size() == 1 || [&] { for (auto& a : t->parts) for (auto& b : t->parts) if (&a != &b && a.c->device == b.c->device) return false; return true; }();
+        t->rec_mode = rec_env == 2 ? REC_MAILBOX : rec_env == 3 ? REC_EVENTS : (distinct ? REC_MAILBOX : REC_EVENTS);
+        t->wait_mode = wait_env == 2 ? WAIT_STREAM : wait_env == 1 ? WAIT_KERNEL : (distinct ? WAIT_KERNEL : WAIT_STREAM);
+        t->halo_mode = halo_env == 3 ? HALO_PUSH : HALO_LOCAL;
+        (void)several_devices;
+    }
+    for (auto& p : t->parts) if (t->halo_mode == HALO_PUSH && p.push.ns < 0) return fail(MI355CG_ERR_STATE, "push halo: a neighbour's memory is not mapped");
+    return MI355CG_OK;
+}
+
 int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
                const volatile int* stop_flag, mi355cg_results* out) {
     if (prm->rule != MI355CG_RULE_MSG_MAXNORM && prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "unknown rule %d", prm->rule);
     if (prm->diagnostics) return fail(MI355CG_ERR_INVALID, "per-iteration diagnostics are not available on a team");
+    if (t->broken) return fail(MI355CG_ERR_STATE, "this team abandoned an earlier solve and cannot be used again");
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
     const IterCfg cfg = make_cfg(prm);             // has_u: u is read on every iteration here (the single-GPU path skips it where unobservable)
-    const int W = t->world;
     const auto t0 = std::chrono::steady_clock::now();
     *t->stop_h = 0;
-    t->split_phases = env_int("MI355CG_TEAM_SPLIT", 0) != 0;
-    t->halo_inline = t->rccl && !t->split_phases && env_int("MI355CG_TEAM_HALO_INLINE", 0) != 0;
+    if (int rc = team_pick_modes(t)) return rc;
+    const bool ev = halo_uses_events(t);
 
     // x = 0, r = b, z = 0; partial norms of r0; first record + halo of r0 = b
+    const u64 seq_init = ++t->seq;
     for (auto& p : t->parts) {
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
@@ -591,25 +936,28 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
             else hipLaunchKernelGGL((k_init_fresh<double, 2, false>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
         }
         if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
-        if (!t->halo_inline) HIPCK(hipEventRecord(p.ev_redge, c->stream));
-        team_record(t, p, 1, c->whole.grid);
+        if (ev) HIPCK(hipEventRecord(p.ev_redge, c->stream));
+        team_record(t, p, 1, c->whole.grid, seq_init);
+        if (int rc = part_push_halo(t, p, seq_init)) return rc;
         HIPCK(hipGetLastError());
         c->solved = true;
     }
-    if (int rc = team_exchange_halo(t)) return rc;
-    if (int rc = team_exchange_records(t, 1)) return rc;
+    if (int rc = team_exchange_halo(t, seq_init)) return rc;
+    if (int rc = team_exchange_records(t, 1, seq_init)) return rc;
 
     TeamPart& lead = t->parts[0];
+    u64 seqB = seq_init;                                           // sequence number of the newest update records
     auto poll_fetch = [&]() -> int {
         HIPCK(hipSetDevice(lead.c->device));
         HIPCK(hipMemcpyAsync(lead.c->summary_h, lead.c->summary, sizeof(CgState), hipMemcpyDeviceToHost, lead.c->stream));
         HIPCK(hipMemcpyAsync(lead.c->hist_h, lead.c->hist, sizeof(HistEntry) * kHist, hipMemcpyDeviceToHost, lead.c->stream));
         HIPCK(hipGetLastError());
-        HIPCK(hipStreamSynchronize(lead.c->stream));
-        return MI355CG_OK;
+        const int rc = bounded_sync(t, lead.c->stream, stop_flag, t->timeout_s + 2e-8 * (double)t->budget_ticks);
+        if (rc < 0) return team_abandon(t, "the lead part's stream did not drain");
+        return rc;
     };
     auto poll = [&]() -> int {
-        for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_poll_enqueue(t, p, cfg)) return rc; }
+        for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_poll_enqueue(t, p, cfg, seqB)) return rc; }
         return poll_fetch();
     };
     // LOCAL transport with several parts: one thread per part (MI355CG_TEAM_THREADS=0: the one-thread loop)
@@ -642,38 +990,50 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     const int every = prm->callback_every;
     int sync_every = std::min(prm->sync_every > 0 ? prm->sync_every : (msg ? 100 : 200), kHist);
     int it_done = 0;
-    bool interrupted = false, first_chunk = cb != nullptr || stop_flag != nullptr;
+    // The chunk schedule is a function of the PARAMETERS only, so it is the same on every rank whatever callbacks or stop flags the
+    // ranks were given: all ranks enqueue the same launches and collectives, poll after the same iterations and leave the loop at the
+    // same poll.  (MSG rule with a callback cadence: the first iteration is a chunk of its own, so the it = 1 callback is delivered
+    // -- and a stop requested from it seen -- before more work is queued.)
+    bool interrupted = false, first_chunk = msg && every > 0;
+    const bool act_at_once = !t->rccl || t->world == 1;            // one process holds every part: nobody else to keep in step
     if (!lead.c->ev_loop[0]) { HIPCK(hipEventCreate(&lead.c->ev_loop[0])); HIPCK(hipEventCreate(&lead.c->ev_loop[1])); }
     HIPCK(hipSetDevice(lead.c->device));
     HIPCK(hipEventRecord(lead.c->ev_loop[0], lead.c->stream));
     while (!lead.c->summary_h->done) {
-        // A stop request has to reach every rank at the same iteration (a rank that left the loop alone would leave the
-        // others waiting in a collective).  One process: act on it at once, like the reference's per-iteration check
-        // (msg_solver.cpp:82-87).  Several: the flag travels with the update records of ONE more iteration and every rank
-        // finds it in its summary at the poll that follows.
+        // A stop request (msg_solver.cpp:82-87).  One process: act on it at once between chunks.  Always: raise the pinned word; it
+        // travels with the next update record of this rank, every rank finds max(stop words) > 0 in the records of that iteration and
+        // takes the decision INTERRUPTED in the same stencil prologue -- in the middle of a chunk, on all ranks at the same iteration.
         const bool want_stop = stop_flag && *stop_flag;
-        if (lead.c->summary_h->pad_ || (want_stop && (!t->rccl || t->world == 1))) { interrupted = true; break; }
+        if (want_stop && act_at_once) { interrupted = true; break; }
         if (want_stop) *t->stop_h = 1;
         int m = std::min(sync_every, prm->max_iterations - it_done);
         if (msg && every > 0) m = std::min(m, every - it_done % every);
-        if (first_chunk || want_stop) { m = 1; first_chunk = false; }
+        if (first_chunk) { m = 1; first_chunk = false; }
         if (m <= 0) m = 1;
         if (crew) {
-            if (int rc = crew->chunk(m, true)) return rc;
+            if (int rc = crew->chunk(m, true, seqB)) return rc;
+            seqB += m; t->seq = seqB;
             if (int rc = poll_fetch()) return rc;
         } else {
             for (int k = 0; k < m; ++k) {
-                for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_stencil_phase(t, p, cfg)) return rc; }
-                if (int rc = team_exchange_records(t, 0)) return rc;
-                for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_update_phase(t, p, cfg)) return rc; }
-                if (int rc = team_exchange_halo(t)) return rc;
-                if (int rc = team_exchange_records(t, 1)) return rc;
+                const u64 seq = ++t->seq;
+                for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_stencil_phase(t, p, cfg, seqB, seq)) return rc; }
+                if (int rc = team_exchange_records(t, 0, seq)) return rc;
+                for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_update_phase(t, p, cfg, seq)) return rc; }
+                if (int rc = team_exchange_halo(t, seq)) return rc;
+                if (int rc = team_exchange_records(t, 1, seq)) return rc;
+                seqB = seq;
             }
             if (int rc = poll()) return rc;
         }
+        if (lead.c->summary_h->done && lead.c->summary_h->reason == kReasonTransport) {
+            t->broken = true;
+            return fail(MI355CG_ERR_STATE, "a part's record did not arrive within %.0f s (MI355CG_TEAM_TIMEOUT_MS): a peer stopped delivering.  The team cannot be used again", t->timeout_s);
+        }
         const int it_now = lead.c->summary_h->it;
         if (msg && cb) for (int it = it_done + 1; it <= it_now; ++it) {
-            const bool stopped_here = lead.c->summary_h->done && lead.c->summary_h->reason != MI355CG_STOP_ITERATIONS && it == it_now;
+            const int reason = lead.c->summary_h->reason;
+            const bool stopped_here = lead.c->summary_h->done && reason != MI355CG_STOP_ITERATIONS && reason != MI355CG_STOP_INTERRUPTED && it == it_now;
             const HistEntry& h = lead.c->hist_h[it % kHist];
             if ((it == 1 || (every > 0 && it % every == 0)) && !stopped_here) cb(user, it, h.dmax, h.rmax, cfg.has_u ? h.emax : DBL_MAX);
         }
@@ -682,15 +1042,24 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     HIPCK(hipSetDevice(lead.c->device));
     HIPCK(hipEventRecord(lead.c->ev_loop[1], lead.c->stream));
     const CgState fin = *lead.c->summary_h;
+    if (fin.done && fin.reason == MI355CG_STOP_INTERRUPTED) interrupted = true;
     for (auto& p : t->parts) {
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
-        if (!t->halo_inline) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));           // the last halo exchange writes this part's ghost cells
+        if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));                       // the last halo exchange writes this part's ghost cells
+        if (int rc = part_wait_halo(t, p, seqB)) return rc;                               // (PUSH: the neighbours' last push has landed before anything else touches r)
         c->cur = fin.it % c->xsteps;
         if (cfg.x2) launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, c->stream);
         HIPCK(hipGetLastError());
     }
-    for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); HIPCK(hipStreamSynchronize(p.c->stream)); HIPCK(hipStreamSynchronize(p.comm)); }
+    for (auto& p : t->parts) {
+        HIPCK(hipSetDevice(p.c->device));
+        for (hipStream_t st : {p.c->stream, p.comm}) {
+            const int rc = bounded_sync(t, st, nullptr, t->timeout_s + 2e-8 * (double)t->budget_ticks);
+            if (rc < 0) return team_abandon(t, "a part's stream did not drain after the last iteration");
+            if (rc) return rc;
+        }
+    }
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (t->profiling) {
         mi355cg_ctx* c = lead.c;
@@ -815,6 +1184,7 @@ int mi355cg_team_create_local(int n, int m, double a, double b, double c_, doubl
         t->parts.push_back(p);
     }
     if (int rc = team_finish_setup(t)) { team_free(t); return rc; }
+    if (int rc = team_build_tables(t)) { team_free(t); return rc; }
     *out = t;
     return MI355CG_OK;
 }
@@ -830,11 +1200,87 @@ int mi355cg_team_unique_id(void* id128) {
     return MI355CG_OK;
 }
 
+namespace {
+// What every rank tells the others at team creation: IPC handles of the three allocations its neighbours write into, and the
+// physical GPU it sits on.
+struct BootRec { hipIpcMemHandle_t slab; char bus[32]; int ok, pad; unsigned long long nonce; };
+// all-gather of `bytes` per rank through the team's communicator (host buffers; staged through device memory)
+int boot_all_gather(mi355cg_team_s* t, const void* mine, void* all, size_t bytes) {
+    TeamPart& p = t->parts[0];
+    unsigned char* d = nullptr;
+    HIPCK(hipMalloc((void**)&d, bytes * t->world));
+    int rc = MI355CG_OK;
+    if (hipMemcpy(d + bytes * p.rank, mine, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail(MI355CG_ERR_HIP, "boot upload failed");
+    if (!rc) {
+        const ncclResult_t r = rccl_api()->AllGather(d + bytes * p.rank, d, bytes, ncclUint8, t->comm, p.comm);
+        if (r != ncclSuccess) rc = fail(MI355CG_ERR_HIP, "ncclAllGather (team bootstrap) failed: %s", rccl_api()->GetErrorString(r));
+    }
+    if (!rc && (hipStreamSynchronize(p.comm) != hipSuccess || hipMemcpy(all, d, bytes * t->world, hipMemcpyDeviceToHost) != hipSuccess)) rc = fail(MI355CG_ERR_HIP, "boot download failed");
+    hipFree(d);
+    return rc;
+}
+// Map every other rank's mailbox / residual / column buffer (IPC).  Collective.  Leaves t->ipc_ok = false (and nothing mapped)
+// when any rank could not export or open a handle, or does not read the owner's bytes through a mapping: the team then runs on
+// RCCL alone.  The check is not paranoia: a handle of re-allocated memory has been seen to resolve to the memory that was there before.
+int team_map_peers(mi355cg_team_s* t) {
+    TeamPart& p = t->parts[0];
+    const int W = t->world;
+    const MboxLayout ml{W};
+    BootRec mine{};
+    char why[160] = "";
+    mine.ok = env_int("MI355CG_TEAM_IPC", 1) != 0 ? 1 : 0;
+    if (!mine.ok) std::snprintf(why, sizeof why, "MI355CG_TEAM_IPC=0");
+    if (mine.ok) {
+        const hipError_t e = hipIpcGetMemHandle(&mine.slab, p.slab);
+        if (e != hipSuccess) { mine.ok = 0; std::snprintf(why, sizeof why, "hipIpcGetMemHandle: %s", hipGetErrorString(e)); (void)hipGetLastError(); }
+    }
+    // a word only this rank could have written (in a cell nothing reads before the first solve writes it)
+    const unsigned long long nonce = ((unsigned long long)getpid() << 32) ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)p.rank << 56);
+    mine.nonce = nonce;
+    HIPCK(hipMemcpy(p.mbox + ml.halo(p.rank), &nonce, sizeof nonce, hipMemcpyHostToDevice));
+    if (hipDeviceGetPCIBusId(mine.bus, sizeof mine.bus, p.c->device) != hipSuccess) { std::snprintf(mine.bus, sizeof mine.bus, "rank%d", p.rank); (void)hipGetLastError(); }
+    std::vector<BootRec> all(W);
+    if (int rc = boot_all_gather(t, &mine, all.data(), sizeof(BootRec))) return rc;
+    t->shared_device = false;
+    bool every = true;
+    for (int i = 0; i < W; ++i) { if (!all[i].ok) every = false; for (int j = 0; j < i; ++j) if (std::strncmp(all[i].bus, all[j].bus, sizeof mine.bus) == 0) t->shared_device = true; }
+    int opened = every ? 1 : 0;
+    if (every) for (int j = 0; j < W && opened; ++j) {
+        if (j == p.rank) continue;
+        void* ps = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&ps, all[j].slab, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { opened = 0; std::snprintf(why, sizeof why, "hipIpcOpenMemHandle(rank %d): %s", j, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
+        p.ipc_opened.push_back(ps);
+        p.peer_mbox[j] = (u64*)ps; p.peer_cols[j] = (double*)((char*)ps + mbox_bytes(W));
+        unsigned long long seen = 0;                                   // does the mapping show what rank j wrote?
+        if (hipMemcpy(&seen, p.peer_mbox[j] + ml.halo(j), sizeof seen, hipMemcpyDeviceToHost) != hipSuccess || seen != all[j].nonce) {
+            opened = 0; std::snprintf(why, sizeof why, "the mapping of rank %d's memory does not show what rank %d wrote (stale IPC mapping)", j, j); (void)hipGetLastError();
+        }
+    }
+    std::vector<int> oks(W, 0);
+    if (int rc = boot_all_gather(t, &opened, oks.data(), sizeof(int))) return rc;            // (also: nobody clears its words before everybody has looked)
+    t->ipc_ok = true;
+    for (int v : oks) if (!v) t->ipc_ok = false;
+    const unsigned long long zero = 0;
+    HIPCK(hipMemcpy(p.mbox + ml.halo(p.rank), &zero, sizeof zero, hipMemcpyHostToDevice));
+    if (!t->ipc_ok) {
+        for (void* q : p.ipc_opened) hipIpcCloseMemHandle(q);
+        p.ipc_opened.clear();
+        for (int j = 0; j < W; ++j) if (j != p.rank) { p.peer_mbox[j] = nullptr; p.peer_cols[j] = nullptr; }
+        (void)hipGetLastError();
+        t->ipc_note = why[0] ? why : "another rank could not map its peers";
+        for (auto& ch : t->ipc_note) if (ch == ' ') ch = '_';
+    }
+    return MI355CG_OK;
+}
+}  // namespace
+
 int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double d, int world, int rank, int device,
                              const void* id128, int decomp, mi355cg_team* out) {
     if (!out) return fail(MI355CG_ERR_INVALID, "out is null");
     *out = nullptr;
     if (rank < 0 || rank >= world || !id128) return fail(MI355CG_ERR_INVALID, "bad rank %d of %d / null id", rank, world);
+    if (world > kMaxRecDst) return fail(MI355CG_ERR_INVALID, "a team has at most %d parts", kMaxRecDst);
     RcclApi* api = rccl_api();
     if (!api) return fail(MI355CG_ERR_HIP, "librccl could not be loaded");
     mi355cg_team_s* t = nullptr;
@@ -851,23 +1297,33 @@ int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double
     if (hipSetDevice(device) != hipSuccess) { team_free(t); return fail(MI355CG_ERR_HIP, "hipSetDevice(%d) failed", device); }
     const ncclResult_t nr = api->CommInitRank(&t->comm, world, id, rank);
     if (nr != ncclSuccess) { t->comm = nullptr; team_free(t); return fail(MI355CG_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(nr)); }
+    if (api->CommCount(t->comm, &t->rccl_nranks) != ncclSuccess) t->rccl_nranks = -1;
     if (world > 1) {
-        // second communicator for the halo messages: its id comes from rank 0 through the first one
-        ncclUniqueId id2;
-        unsigned char* dbuf = nullptr;
-        auto bail = [&](const char* what, const char* why) { if (dbuf) hipFree(dbuf); team_free(t); return fail(MI355CG_ERR_HIP, "%s failed: %s", what, why); };
-        if (rank == 0) { const ncclResult_t r0 = api->GetUniqueId(&id2); if (r0 != ncclSuccess) return bail("ncclGetUniqueId", api->GetErrorString(r0)); }
-        if (hipMalloc((void**)&dbuf, sizeof id2) != hipSuccess) return bail("hipMalloc", "id buffer");
-        if (rank == 0 && hipMemcpy(dbuf, &id2, sizeof id2, hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy", "id upload");
-        hipStream_t st = t->parts[0].comm;
-        const ncclResult_t rb = api->Broadcast(dbuf, dbuf, sizeof id2, ncclUint8, 0, t->comm, st);
-        if (rb != ncclSuccess) return bail("ncclBroadcast", api->GetErrorString(rb));
-        if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(&id2, dbuf, sizeof id2, hipMemcpyDeviceToHost) != hipSuccess) return bail("hipMemcpy", "id download");
-        hipFree(dbuf); dbuf = nullptr;
-        const ncclResult_t n2 = api->CommInitRank(&t->comm_halo, world, id2, rank);
-        if (n2 != ncclSuccess) { t->comm_halo = nullptr; return bail("ncclCommInitRank (halo communicator)", api->GetErrorString(n2)); }
+        if ((rc = team_map_peers(t))) { team_free(t); return rc; }
+        // A second communicator only where the halo is asked to travel on RCCL beside the records (MI355CG_TEAM_HALO=stream):
+        // its id comes from rank 0 through the first one
+        if (env_choice("MI355CG_TEAM_HALO", {"auto", "inline", "stream", "push"}, 0) == 2) {
+            ncclUniqueId id2{};
+            if (rank == 0) { const ncclResult_t r0 = api->GetUniqueId(&id2); if (r0 != ncclSuccess) { team_free(t); return fail(MI355CG_ERR_HIP, "ncclGetUniqueId failed: %s", api->GetErrorString(r0)); } }
+            std::vector<ncclUniqueId> ids(world);
+            if ((rc = boot_all_gather(t, &id2, ids.data(), sizeof id2))) { team_free(t); return rc; }
+            const ncclResult_t n2 = api->CommInitRank(&t->comm_halo, world, ids[0], rank);
+            if (n2 != ncclSuccess) { t->comm_halo = nullptr; team_free(t); return fail(MI355CG_ERR_HIP, "ncclCommInitRank (halo communicator) failed: %s", api->GetErrorString(n2)); }
+        }
     }
+    if ((rc = team_build_tables(t))) { team_free(t); return rc; }
     *out = t;
+    return MI355CG_OK;
+}
+
+// "transport=rccl records=mailbox wait=kernel halo=push ipc=1 shared_device=0 rccl_nranks=8 rccl_lib=librccl.so.1": what the next
+// solve of this team will use (environment + what the ranks found out about each other at creation)
+int mi355cg_team_describe(mi355cg_team t, char* buf, int len) {
+    if (!t || !buf || len <= 0) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (int rc = team_pick_modes(t)) return rc;
+    std::snprintf(buf, (size_t)len, "transport=%s records=%s wait=%s halo=%s split=%d ipc=%d shared_device=%d rccl_nranks=%d rccl_lib=%s ipc_note=%s",
+                  t->rccl ? "rccl" : "local", rec_name(t->rec_mode), wait_name(t->wait_mode), halo_name(t->halo_mode), t->split_phases ? 1 : 0,
+                  t->ipc_ok ? 1 : 0, t->shared_device ? 1 : 0, t->rccl_nranks, t->rccl && rccl_api() ? rccl_api()->lib_name.c_str() : "-", t->ipc_note.c_str());
     return MI355CG_OK;
 }
 

@@ -468,6 +468,15 @@ class Team:
     def setup_on_device(self):
         _capi.check(self._lib.mi355cg_team_setup_on_device(self._h))
 
+    def describe(self) -> dict:
+        """What the next solve uses: {"transport", "records", "wait", "halo", "split", "ipc", "shared_device", "rccl_nranks", "rccl_lib"}."""
+        buf = C.create_string_buffer(512)
+        _capi.check(self._lib.mi355cg_team_describe(self._h, buf, len(buf)))
+        out = dict(kv.split("=", 1) for kv in buf.value.decode().split())
+        for k in ("split", "ipc", "shared_device", "rccl_nranks"):
+            out[k] = int(out[k])
+        return out
+
     def set_profiling(self, on: bool):
         _capi.check(self._lib.mi355cg_team_set_profiling(self._h, 1 if on else 0))
 

@@ -1,0 +1,129 @@
+"""CPU tests of bench.py's multi-GPU launcher: the legs it plans, the environment and command line every rank process gets,
+and the coordinator itself -- started without a launcher (it spawns all N ranks) and as one of a launcher's N workers (it
+spawns its own rank only) -- with stand-in rank processes: records collected from rank 0, a stalled leg killed at its time
+limit without losing the legs before or after it, a failing rank reported.  No GPU is touched: the coordinator never imports torch."""
+import json
+import os
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _args(**kw):
+    a = types.SimpleNamespace(gpus=8, steps=20, warmup=5, n=4096, rule="rel2", dtype="f64", scaling="weak", decomp="rows", cpu_iters=0,
+                              no_roofline_pass=False, repeats=0, verify=30, verify_max_unknowns=2.6e8, legs="all", leg_timeout=20.0, budget=900.0,
+                              child_leg=None, child_out=None)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_the_coordinator_cannot_touch_a_gpu():
+    assert "torch" not in [m.split(".")[0] for m in bench.coordinate.__code__.co_names]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def run_leg_child")]
+    assert "import torch" not in head and "iterative_solvers_amd" not in head.replace("iterative_solvers_amd.distributed.weak_scaling_n", "")
+
+
+def test_legs_of_an_eight_gpu_run():
+    legs = bench.plan_legs(_args())
+    names = [l["name"] for l in legs]
+    assert names[:2] == ["rccl-inline", "mailbox+push"]                 # the order-safe schedule is timed first
+    assert [l["name"] for l in legs if l["headline"]] == ["rccl-inline", "mailbox+push"]
+    assert "config5-strong-32768" in names and names[-1] == "local-one-process" and "config4-2x2-16384" not in names
+    strong = next(l for l in legs if l["name"] == "config5-strong-32768")
+    assert (strong["scaling"], strong["grid"], strong["decomp"]) == ("strong", 32768, "rows")
+    four = bench.plan_legs(_args(gpus=4))
+    c4 = next(l for l in four if l["name"] == "config4-2x2-16384")
+    assert (c4["scaling"], c4["grid"], c4["decomp"]) == ("strong", 16384, "2d")
+    assert [l["name"] for l in bench.plan_legs(_args(legs="default"))] == ["rccl-inline", "mailbox+push"]
+    assert [l["name"] for l in bench.plan_legs(_args(gpus=1))][-1] != "local-one-process"
+
+
+def test_rank_environment_and_command_line():
+    base = {"PATH": os.environ["PATH"], "TORCHELASTIC_RUN_ID": "x", "MI355CG_TEAM_HALO": "stream", "LOCAL_WORLD_SIZE": "8", "MASTER_PORT": "29400"}
+    spec = bench.plan_legs(_args())[0]
+    env = bench.leg_env(base, spec, rank=3, world=8, local_rank=3, port=29999)
+    assert (env["RANK"], env["WORLD_SIZE"], env["LOCAL_RANK"], env["MASTER_ADDR"], env["MASTER_PORT"]) == ("3", "8", "3", "127.0.0.1", "29999")
+    assert env["MI355CG_TEAM_RECORDS"] == "rccl" and env["MI355CG_TEAM_HALO"] == "inline" and env["MI355CG_BENCH_CHILD"] == "1"
+    assert "TORCHELASTIC_RUN_ID" not in env and "LOCAL_WORLD_SIZE" not in env and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    env2 = bench.leg_env(base, bench.plan_legs(_args())[1], 0, 8, 0, 30000)
+    assert env2["MI355CG_TEAM_RECORDS"] == "auto" and env2["MI355CG_TEAM_HALO"] == "auto" and "MI355CG_TEAM_IPC" not in env2
+    cmd = bench.leg_command(_args(), spec, "/tmp/x")
+    assert cmd[0] == sys.executable and cmd[1].endswith("bench.py")
+    assert cmd[cmd.index("--gpus") + 1] == "8" and cmd[cmd.index("--steps") + 1] == "20" and json.loads(cmd[cmd.index("--child-leg") + 1])["name"] == "rccl-inline"
+
+
+# a stand-in for a rank process: behaves as the leg's name says and writes rank 0's record
+STUB = r"""
+import json, os, sys, time
+spec = json.loads(sys.argv[sys.argv.index("--child-leg") + 1]); out = sys.argv[sys.argv.index("--child-out") + 1]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if spec["name"] == "rccl-stream":
+    time.sleep(600)                                    # a collective that never completes
+if spec["name"] == "config5-strong-32768" and rank == world - 1:
+    json.dump({"leg": spec["name"], "error": "rank %d: boom" % rank}, open(out + ".r%d" % rank, "w")); sys.exit(1)
+if spec["name"] == "config5-strong-32768":
+    time.sleep(600)                                    # the other ranks wait for the dead one
+if rank == 0:
+    json.dump({"leg": spec["name"], "value": {"rccl-inline": 50000.0, "mailbox+push": 56000.0}.get(spec["name"], 1.0), "n_gpus": world, "global_iters_per_sec": 7000.0,
+               "ms_per_step": 0.143, "repeats": 11, "ms_per_step_min_max": [0.14, 0.15], "n": 11586, "unknowns": 100629441, "unknowns_per_gpu": 1.0,
+               "decomposition": {"kind": "rows", "parts": []}, "transport": {"rccl_nranks": world, "port": os.environ["MASTER_PORT"], "records": os.environ.get("MI355CG_TEAM_RECORDS")},
+               "hbm_gbps": 1.0, "per_gpu_gbps": 5000.0, "per_gpu_frac_of_8000": 0.625, "phases_ms": {}, "verify_against_one_gpu": {"ok": spec["name"] != "mailbox+push" or os.environ.get("STUB_PUSH_OK", "1") == "1"}},
+              open(out + ".r0", "w"))
+"""
+
+
+@pytest.fixture
+def stub(tmp_path, monkeypatch):
+    path = tmp_path / "stub_rank.py"
+    path.write_text(STUB)
+    real = bench.leg_command
+    monkeypatch.setattr(bench, "leg_command", lambda args, spec, out: [sys.executable, str(path)] + real(args, spec, out)[2:])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29600")
+    return path
+
+
+def test_coordinator_without_a_launcher_runs_every_leg_and_survives_a_stall(stub):
+    args = _args(gpus=4, leg_timeout=3.0)
+    legs, results, notes = bench.coordinate(args)
+    assert list(results) == [l["name"] for l in legs]
+    assert results["rccl-inline"]["value"] == 50000.0 and results["mailbox+push"]["n_gpus"] == 4
+    assert "stalled" in results["rccl-stream"]["error"]                  # killed at its limit ...
+    assert "boom" in results["config5-strong-32768"]["error"]            # ... a dead rank is reported, its peers are not waited for
+    assert results["config4-2x2-16384"]["value"] == 1.0 and results["local-one-process"]["n_gpus"] == 1      # ... and the legs behind them still ran
+    ports = [results[n]["transport"]["port"] for n in ("rccl-inline", "mailbox+push")]
+    assert len(set(ports)) == 2 and all(int(p) > 29600 for p in ports)   # every leg meets on a port of its own, none on the launcher's
+    out = bench.compose(args, legs, results, notes)
+    assert out["n_gpus"] == 4 and out["value"] == 56000.0 and out["headline_leg"] == "mailbox+push" and out["rccl_nranks"] == 4
+    assert out["roofline"]["frac"] == 0.625 and set(out["legs"]) == set(results) and out["scaling"] == "weak"
+
+
+def test_an_unverified_leg_is_not_the_headline(stub, monkeypatch):
+    monkeypatch.setenv("STUB_PUSH_OK", "0")
+    args = _args(gpus=2, legs="default", leg_timeout=5.0)
+    out = bench.compose(args, *bench.coordinate(args))
+    assert out["headline_leg"] == "rccl-inline" and out["value"] == 50000.0
+    assert out["legs"]["mailbox+push"]["verify_against_one_gpu"]["ok"] is False
+
+
+def test_coordinator_as_a_launcher_worker_starts_only_its_own_rank(stub, monkeypatch, tmp_path):
+    args = _args(gpus=2, legs="default", leg_timeout=5.0)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    assert bench.coordinate(args) is None                                # not the lead: prints nothing
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    legs, results, notes = bench.coordinate(args)
+    assert results["rccl-inline"]["n_gpus"] == 2 and results["rccl-inline"]["transport"]["records"] == "rccl"
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit):
+        bench.coordinate(args)                                           # the launcher's world and --gpus disagree
