@@ -142,6 +142,7 @@ struct RuleParams {
 enum { FA_PAP = 0, FA_RZ = 1, FA_LO = 2, FA_COUNT = 4 };
 enum { FB_RR = 0, FB_D2 = 1, FB_E2 = 2, FB_LO = 3, FB_RMAX = 6, FB_DMAX = 7, FB_EMAX = 8, FB_COUNT = 9 };
 constexpr int kNumSumsA = 2, kNumSumsB = 3;          // sum fields come first, then their lo words, then the max fields
+constexpr int FB_STOP = FB_COUNT, FB_LL_COUNT = FB_COUNT + 1;   // flagged update partials carry one more field: the stop request the launch sampled (its block 0; 0 elsewhere)
 
 // ---- double-double accumulation of the inner products ------------------------------------------------
 // Every inner product is accumulated as an unevaluated pair hi + lo (Knuth TwoSum, FMA TwoProduct): the
@@ -332,55 +333,77 @@ __device__ inline Decision reduce_and_decide(const StateLite& s, const RuleParam
     }
     return decide_after_update(s, rp, rr, rmax, dmax, emax, d2, e2);
 }
-// ---- a part's record, written by the LAST block of the last launch of a phase (teams, csrc/team.h) ------------------
-// Record = the part's partials reduced in slot order (sums as hi/lo pairs, then the maxes) + its stop request: what
-// crosses parts after each phase.  Producing it in the producer launch itself (arrival ticket, last arriver reduces)
-// instead of a separate one-block launch takes a launch boundary and a kernel off the critical path
-// producer -> record -> consumer.
-//
-// A record travels in FLAGGED form: its 16 doubles are cut into 32 words of 32 data bits, each stored as one 64-bit word
-// {stamp << 32 | data} with a single-copy-atomic system-scope store.  A consumer knows a word has arrived when it carries
-// the stamp it expects (the team-wide iteration sequence number), so no fence orders the words with anything: the
-// producer's last block stores them straight into the mailbox of every part (its own GPU's memory, a peer GPU's over
-// xGMI, another process's through an IPC mapping) and the consumer launch polls its LOCAL mailbox in its prologue.
-// That is the whole hop: no collective, no event, no second launch.  (RCCL's LL protocol is the same idea; with the RCCL
-// all-gather as the transport the flagged words are what is gathered and the poll succeeds at once.)
+// ---- what crosses the parts of a team after each phase (csrc/team.h) -------------------------------------------------
+// A part's RECORD = its partials reduced in slot order (sums as hi/lo pairs, then the maxes) + its stop request: 16 doubles.
+// Everything a launch hands to another launch that is NOT ordered behind it by a stream travels in FLAGGED form: a double is
+// cut into two words of 32 data bits, each stored as one 64-bit word {stamp << 32 | data} with a single-copy-atomic
+// system-scope store.  A reader knows a word has arrived when it carries the stamp it expects (the team-wide iteration
+// sequence number), so no fence orders the words with anything.  Two hops use it:
+//   * every block of a producer launch also stores its partials flagged (FlagSpec).  A one-block REDUCER launch (k_reduce_ll)
+//     runs beside the producer on another stream, polls those words, reduces them in the consumers' order and stores the
+//     part's record -- flagged -- straight into the mailbox of every OTHER part (a peer GPU's memory over xGMI; IPC-mapped
+//     when that part is another process).  The producer launch carries no tail work for it and ends when its items end.
+//   * a consumer launch reduces its OWN part's partials itself (they were written by the launch before it on its stream),
+//     polls its mailbox for the other parts' records (bounded) and combines all parts in part order, so every part takes
+//     the same decision.  By the time it is launched the neighbours' reducers have usually delivered.
+// No collective, no event and no extra launch sits on the path producer -> consumer.  (RCCL's LL protocol is the same idea; with
+// the RCCL all-gather as the transport the flagged records are what is gathered and the poll succeeds at once.)
 typedef unsigned long long u64;
 constexpr int kRecWords = 16;                     // doubles per record
 constexpr int kLLWords = 2 * kRecWords;           // 64-bit flagged words per record
 constexpr int kRecStopWord = 9;                   // word that carries a rank's stop request (max over ranks = stop everywhere)
 constexpr int kMaxRecDst = 16;
 constexpr int kReasonTransport = 5;               // internal stop reason: a record did not arrive within the budget (-> MI355CG_ERR_STATE)
+constexpr int kMaxPartSlots = 1024;               // partial slots of one phase the reducer can take (interior + edge launches <= 2 x 512 blocks)
 __device__ inline u64 ld_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline void st_sys(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline u64 flagged(unsigned stamp, unsigned data) { return ((u64)stamp << 32) | data; }
 
+// A producer launch's flagged partials: slot-major, [slot][2 * fields] words (field f of a block: words 2f = low half, 2f + 1 = high half)
+struct FlagSpec {
+    u64* part;                                    // nullptr: this launch has no reader outside its stream
+    unsigned stamp;
+};
+__device__ inline void store_flagged(const FlagSpec& fs, int slot, int nfields, const double* v) {      // one thread; v: the block's partials, field order
+    u64* w = fs.part + (long long)slot * (2 * nfields);
+    for (int f = 0; f < nfields; ++f) {
+        const u64 bits = __builtin_bit_cast(u64, v[f]);
+        st_sys(w + 2 * f, flagged(fs.stamp, (unsigned)bits));
+        st_sys(w + 2 * f + 1, flagged(fs.stamp, (unsigned)(bits >> 32)));
+    }
+}
+// a launch that ends in its prologue (the solve is over) still owes the reducer its words: zeros
+__device__ inline void store_flagged_zero(const FlagSpec& fs, int slot, int nfields) {
+    if (!fs.part) return;
+    u64* w = fs.part + (long long)slot * (2 * nfields);
+    for (int k = 0; k < 2 * nfields; ++k) st_sys(w + k, flagged(fs.stamp, 0u));
+}
+
+// Where a part's record goes.
 struct RecSpec {
-    int enabled;                                  // 0: this launch does not end a phase of a team
-    int nslots;                                   // partial slots of the whole phase (interior + edge launches)
-    unsigned* ticket;                             // arrival counter, 0 between launches
-    const int* stop_req;                          // pinned host word (update phase), may be null
     int ndst;
     u64* const* dst;                              // DEVICE array: this part's record (slot 0) in the mailbox of every destination part
-                                                  // (an array inside the by-value kernel arguments would be spilled as soon as it is indexed at run time)
     u64* const* flag;                             // DEVICE array or null: per destination, the word a STREAM-level wait of the consumer watches
     int slot_words;                               // 64-bit words from slot 0 to slot 1 of a mailbox
     int slot;                                     // the slot of this record (iteration sequence number & 1)
     unsigned seq;                                 // stamp of this record (never 0)
     u64 flag_value;                               // what the announcement words get: the sequence number itself
 };
-// Where a consumer launch finds the records of the phase before it.
+// Where a consumer launch finds the OTHER parts' records of the phase before it.
 struct RecSrc {
-    const u64* mbox;                              // [world][kLLWords] (the slot this launch reads); nullptr: legacy per-block partials
-    int world;
+    const u64* mbox;                              // [world][kLLWords] (the slot this launch reads); nullptr: not a team launch
+    int world, me;                                // me: this part (its own record is not awaited: the launch reduces its own partials)
     unsigned stamp;
     u64 budget;                                   // wall_clock64 ticks (100 MHz) this launch may wait for a word
 };
-// All threads of a block.  recs: LDS, [world][kRecWords] doubles.  Returns false when a word did not show up in time.
+// All threads of a block.  recs: LDS, [world][kRecWords] doubles; slot `me` is left alone.  Returns false when a word did not
+// show up in time.  Ends with a barrier: what other threads wrote into recs before the call is visible after it.
 __device__ inline bool gather_records(const RecSrc& src, double* recs) {
     unsigned* out = reinterpret_cast<unsigned*>(recs);
     const int n = src.world * kLLWords;
     int bad = 0;
     for (int i = threadIdx.x; i < n; i += kBlock) {
+        if (i / kLLWords == src.me) continue;
         u64 v = ld_sys(src.mbox + i);
         if ((unsigned)(v >> 32) != src.stamp) {
             const u64 t0 = wall_clock64();
@@ -396,74 +419,74 @@ __device__ inline bool gather_records(const RecSrc& src, double* recs) {
     }
     return __syncthreads_or(bad) == 0;
 }
-// A block's partial: a plain store, or -- when another block of the SAME launch will read it (team record) -- a
-// write-through store at agent scope (cdna_hip_programming.md Guideline 16, R1: sc1 payload, drain, ticket; NO release
-// fence: on this 8-XCD part an agent-scope release writes back the whole dirty L2, i.e. the launch's own output stream,
-// once per block -- measured 2x on the launch).
-__device__ inline void store_partial(double* p, double v, bool publish) {
-    if (publish) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
 // rec (LDS, kRecWords doubles) -> flagged words in every destination's mailbox
 __device__ inline void publish_record(const double* rec, const RecSpec& rs) {
     const unsigned* half = reinterpret_cast<const unsigned*>(rec);
     const long long slot = (long long)rs.slot * rs.slot_words;
     for (int i = threadIdx.x; i < rs.ndst * kLLWords; i += kBlock)
-        st_sys(rs.dst[i / kLLWords] + slot + i % kLLWords, ((u64)rs.seq << 32) | half[i % kLLWords]);
+        st_sys(rs.dst[i / kLLWords] + slot + i % kLLWords, flagged(rs.seq, half[i % kLLWords]));
     if (rs.flag && (int)threadIdx.x < rs.ndst) st_sys(rs.flag[threadIdx.x], rs.flag_value);
 }
-// which: 0 = stencil partials (FA_*), 1 = update partials (FB_*).  Called by all threads of one block.
-// All loads of all fields are issued first (one memory round trip instead of one per field), then reduced field by field
-// in reduce_parts_dd's order.
-__device__ inline void emit_record(int which, const double* part, int stride, const RecSpec& rs, double* lds) {
+
+// ---- the reducer: flagged partials of one phase -> the part's record in the other parts' mailboxes --------------------
+// One block.  Runs beside the producer launch(es) of the phase (its own stream) or behind them (same stream); either way it
+// only believes stamped words.  The reduction is reduce_parts_dd's / reduce_parts<true>'s, slot for slot, so the record carries
+// exactly the pairs a consumer of the same part computes for itself from the plain partials.
+struct ReduceArgs {
+    const u64* part; int nslots, which;           // which: 0 = stencil partials (FA_*), 1 = update partials (FB_*)
+    unsigned stamp; u64 budget;
+    RecSpec rs;
+};
+__global__ __launch_bounds__(kBlock) void k_reduce_ll(const ReduceArgs a) {
+    __shared__ double vals[FB_LL_COUNT * kMaxPartSlots];   // field-major: vals[f * nslots + slot]
+    __shared__ double lds[2 * kWaves];
     __shared__ double rec[kRecWords];
+    const int nf = a.which == 0 ? FA_COUNT : FB_LL_COUNT, n = a.nslots;
     if (threadIdx.x < kRecWords) rec[threadIdx.x] = 0.0;
-    int stop_word = 0;                            // a read of pinned HOST memory: issued first, so it travels beside the partial loads
-    if (which == 1 && threadIdx.x == 0 && rs.stop_req) stop_word = *(const volatile int*)rs.stop_req;
-    const int nsum = which == 0 ? kNumSumsA : kNumSumsB, lo_off = which == 0 ? FA_LO : FB_LO;
-    constexpr int kMaxSums = 3;
-    PreParts pre[kMaxSums];
-    PreMax pmax[3] = {{0, 0}, {0, 0}, {0, 0}};
-#pragma unroll
-    for (int f = 0; f < kMaxSums; ++f) if (f < nsum) pre[f] = prefetch_parts(part + f * stride, part + (f + lo_off) * stride, rs.nslots, 1);
-    if (which == 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) pmax[k] = prefetch_max(part + (FB_RMAX + k) * stride, rs.nslots, 1);
+    unsigned* out = reinterpret_cast<unsigned*>(vals);
+    const int nw = n * 2 * nf;
+    int bad = 0;
+    const u64 t0 = wall_clock64();
+    for (int i = threadIdx.x; i < nw && !bad; i += kBlock) {
+        u64 v = ld_sys(a.part + i);
+        unsigned spins = 0;
+        for (;;) {
+            // a stamp is 0x80000000 | (sequence number mod 2^31); 0 = never written.  A NEWER stamp: the launches of a later iteration
+            // have already overwritten the words -- only possible once the solve is over and launches return in their prologue -- so
+            // nobody waits for this record any more.
+            const unsigned st = (unsigned)(v >> 32);
+            const int ahead = (st & 0x80000000u) ? (int)((st - a.stamp) << 1) : -1;
+            if (ahead == 0) break;
+            if (ahead > 0) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+            v = ld_sys(a.part + i);
+            if ((++spins & 31u) == 0 && wall_clock64() - t0 > a.budget) { bad = 1; break; }
+        }
+        const int slot = i / (2 * nf), w = i - slot * (2 * nf);
+        out[2 * ((w >> 1) * n + slot) + (w & 1)] = (unsigned)v;
     }
-    __syncthreads();
-#pragma unroll
-    for (int f = 0; f < kMaxSums; ++f) if (f < nsum) {
-        const dd t = reduce_parts_dd_pre(pre[f], part + f * stride, part + (f + lo_off) * stride, rs.nslots, 1, lds);
+    if (__syncthreads_or(bad)) return;            // superseded, or timed out: then the consumers miss the record too and end the solve
+    const int nsum = a.which == 0 ? kNumSumsA : kNumSumsB, lo_off = a.which == 0 ? FA_LO : FB_LO;
+    for (int f = 0; f < nsum; ++f) {
+        const dd t = reduce_parts_dd(vals + f * n, vals + (f + lo_off) * n, n, 1, lds);
         if (threadIdx.x == 0) { rec[f] = t.hi; rec[f + lo_off] = t.lo; }
     }
-    if (which == 1) {
-#pragma unroll
+    if (a.which == 1) {
         for (int k = 0; k < 3; ++k) {
-            const double t = reduce_max_pre(pmax[k], part + (FB_RMAX + k) * stride, rs.nslots, 1, lds);
+            const double t = reduce_parts<true>(vals + (FB_RMAX + k) * n, n, 1, lds);
             if (threadIdx.x == 0) rec[FB_RMAX + k] = t;
         }
-        if (threadIdx.x == 0) rec[kRecStopWord] = stop_word ? 1.0 : 0.0;
+        // the stop request as the update launch itself sampled it (the launch's own part acts on the same sample through its state)
+        const double t = reduce_parts<true>(vals + FB_STOP * n, n, 1, lds);
+        if (threadIdx.x == 0) rec[kRecStopWord] = t;
     }
     __syncthreads();
-    publish_record(rec, rs);
+    publish_record(rec, a.rs);
 }
-// Epilogue of a producer launch; thread 0 has just stored this block's partials with store_partial(..., true).
-// Returns after the last block emitted the record.
-__device__ inline void arrive_and_record(int which, const double* part, int stride, const RecSpec& rs, double* lds) {
-    if (!rs.enabled) return;
-    __shared__ int last;
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-through partials have landed before the ticket
-        last = __hip_atomic_fetch_add(rs.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // drop this CU's / XCD's stale lines once, then plain loads
-    emit_record(which, part, stride, rs, lds);
-    if (threadIdx.x == 0) __hip_atomic_store(rs.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+
 // ---- the consumer side: the phase's scalars from the parts' records, in part order -------------------------------
-__device__ inline Decision decide_from_records(const StateLite& s, const RuleParams& rp, const double* recs, int world) {
+// recs[me] was filled by the caller from the part's own partials; use_max: the rule (or the summary) looks at the max-norms
+__device__ inline Decision decide_from_records(const StateLite& s, const RuleParams& rp, const double* recs, int world, bool use_max, bool want_diag) {
     dd rr = dd_zero(), d2 = dd_zero(), e2 = dd_zero();
     double rmax = 0, dmax = 0, emax = 0, stop = 0;
     for (int j = 0; j < world; ++j) {
@@ -474,7 +497,10 @@ __device__ inline Decision decide_from_records(const StateLite& s, const RulePar
         rmax = fmax(rmax, R[FB_RMAX]); dmax = fmax(dmax, R[FB_DMAX]); emax = fmax(emax, R[FB_EMAX]);
         stop = fmax(stop, R[kRecStopWord]);
     }
-    return decide_after_update(s, rp, dd_value(rr), rmax, dmax, rp.use_u ? emax : 0.0, dd_value(d2), rp.use_u ? dd_value(e2) : 0.0, stop > 0.0);
+    if (!use_max) { rmax = 0; dmax = 0; emax = 0; }
+    if (!rp.use_u) { emax = 0; e2 = dd_zero(); }
+    if (!want_diag) { d2 = dd_zero(); e2 = dd_zero(); }
+    return decide_after_update(s, rp, dd_value(rr), rmax, dmax, emax, dd_value(d2), dd_value(e2), stop > 0.0);
 }
 __device__ inline void alpha_from_records(const StateLite& s, int rule, const double* recs, int world, double* alpha, double* rz_out) {
     dd pap = dd_zero(), rz = dd_zero();
@@ -486,12 +512,36 @@ __device__ inline void alpha_from_records(const StateLite& s, int rule, const do
     if (rule == 0) { *rz_out = dd_value(rz); *alpha = *rz_out / dd_value(pap); }       // msg_solver.cpp:102
     else { *rz_out = 0.0; *alpha = s.rr / dd_value(pap); }                             // matrix_free_system.cpp:419
 }
-// A producer launch that ends in its prologue (the solve is over) publishes no record, but consumers whose STREAMS wait for the
-// announcement word of this phase (WAIT_STREAM) were enqueued regardless: one thread announces without a record.  The consumer
-// launches behind those waits return in their own prologue before they look at the mailbox.
-__device__ inline void announce_only(const RecSpec& rs) {
-    if (!rs.enabled || !rs.flag) return;
-    for (int d = 0; d < rs.ndst; ++d) st_sys(rs.flag[d], rs.flag_value);
+// This part's own update-phase record fields from its plain partials (the reductions of reduce_and_decide, kept as pairs), into
+// recs[me].  level 0: r.r only; 1: + the max-norms; 2: everything (summary).  All threads of the block.
+__device__ inline void own_record_B(double* recs, int me, const double* partB, int nB, int strideB, int level, double* lds,
+                                    const PreParts* pre_rr = nullptr, const PreMax* pre_max = nullptr) {
+    double* R = recs + me * kRecWords;
+    if (threadIdx.x < kRecWords) R[threadIdx.x] = 0.0;
+    const dd rr = pre_rr ? reduce_parts_dd_pre(*pre_rr, partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, 1, lds)
+                         : reduce_parts_dd(partB + FB_RR * strideB, partB + (FB_RR + FB_LO) * strideB, nB, 1, lds);
+    double rmax = 0, dmax = 0, emax = 0;
+    dd d2 = dd_zero(), e2 = dd_zero();
+    if (level >= 1) {
+        if (pre_max) {
+            rmax = reduce_max_pre(pre_max[0], partB + FB_RMAX * strideB, nB, 1, lds);
+            dmax = reduce_max_pre(pre_max[1], partB + FB_DMAX * strideB, nB, 1, lds);
+            emax = reduce_max_pre(pre_max[2], partB + FB_EMAX * strideB, nB, 1, lds);
+        } else {
+            rmax = reduce_parts<true>(partB + FB_RMAX * strideB, nB, 1, lds);
+            dmax = reduce_parts<true>(partB + FB_DMAX * strideB, nB, 1, lds);
+            emax = reduce_parts<true>(partB + FB_EMAX * strideB, nB, 1, lds);
+        }
+    }
+    if (level >= 2) {
+        d2 = reduce_parts_dd(partB + FB_D2 * strideB, partB + (FB_D2 + FB_LO) * strideB, nB, 1, lds);
+        e2 = reduce_parts_dd(partB + FB_E2 * strideB, partB + (FB_E2 + FB_LO) * strideB, nB, 1, lds);
+    }
+    __syncthreads();                                   // the zero fill above is done
+    if (threadIdx.x == 0) {
+        R[FB_RR] = rr.hi; R[FB_RR + FB_LO] = rr.lo; R[FB_D2] = d2.hi; R[FB_D2 + FB_LO] = d2.lo; R[FB_E2] = e2.hi; R[FB_E2 + FB_LO] = e2.lo;
+        R[FB_RMAX] = rmax; R[FB_DMAX] = dmax; R[FB_EMAX] = emax;
+    }
 }
 // a launch whose records did not arrive: the solve ends here with an internal reason the host turns into an error
 __device__ inline void fail_transport(CgState* out, const CgState* in) {
@@ -517,7 +567,7 @@ struct StencilArgs {
     int want_diag;
     int store_ghosts;    // part of a decomposed grid: also store p_new of the ghost rows (recomputed from the local ghost copies
                          // of r and p_old, bit-identical to the neighbour's rows), so the direction never has to cross ranks
-    RecSpec rec;         // team: this launch ends the stencil phase -> its last block writes the part's record
+    FlagSpec fl;         // team: every block also stores its partials flagged, for the reducer launch that runs beside this one
 };
 
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
@@ -724,16 +774,29 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
 
     T beta = (T)0;
     if (FUSED && a.src.mbox) {
-        // team: the decision comes from the parts' records (one poll of the local mailbox), not from per-block partials
+        // team: this part's share of the sums comes from its own partials (as on a single GPU), the other parts' from their records
         __shared__ double recs[kMaxRecDst * kRecWords];
+        const PreParts pre = prefetch_parts(a.partB + FB_RR * a.strideB, a.partB + (FB_RR + FB_LO) * a.strideB, a.nB, 1);
+        PreMax pmax[3] = {{0, 0}, {0, 0}, {0, 0}};
+        if (MSG) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pmax[k] = prefetch_max(a.partB + (FB_RMAX + k) * a.strideB, a.nB, 1);
+        }
         const StateLite s = load_state_lite(a.s_in);
-        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) { copy_state(a.s_out, a.s_in); announce_only(a.rec); } return; }
+        if (s.done) {
+            if (threadIdx.x == 0) { store_flagged_zero(a.fl, a.slotA + blockIdx.x, FA_COUNT); if (blockIdx.x == 0) copy_state(a.s_out, a.s_in); }
+            return;
+        }
         MI355CG_WT_STAMP(1)
-        if (!gather_records(a.src, recs)) { if (blockIdx.x == 0 && threadIdx.x == 0) { fail_transport(a.s_out, a.s_in); announce_only(a.rec); } return; }
-        const Decision d = decide_from_records(s, a.rp, recs, a.src.world);
+        own_record_B(recs, a.src.me, a.partB, a.nB, a.strideB, MSG ? 1 : 0, lds, &pre, MSG ? pmax : nullptr);
+        if (!gather_records(a.src, recs)) {
+            if (threadIdx.x == 0) { store_flagged_zero(a.fl, a.slotA + blockIdx.x, FA_COUNT); if (blockIdx.x == 0) fail_transport(a.s_out, a.s_in); }
+            return;
+        }
+        const Decision d = decide_from_records(s, a.rp, recs, a.src.world, MSG, false);
         MI355CG_WT_STAMP(2)
-        if (blockIdx.x == 0 && threadIdx.x == 0) { write_state_after_decision(a.s_out, a.hist, a.s_in, s, d); if (d.done) announce_only(a.rec); }
-        if (d.done) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) write_state_after_decision(a.s_out, a.hist, a.s_in, s, d);
+        if (d.done) { if (threadIdx.x == 0) store_flagged_zero(a.fl, a.slotA + blockIdx.x, FA_COUNT); return; }
         beta = (T)d.beta;
     } else if (FUSED) {
         const PreParts pre = prefetch_parts(a.partB + FB_RR * a.strideB, a.partB + (FB_RR + FB_LO) * a.strideB, a.nB, a.esB);
@@ -823,11 +886,10 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     if (MSG) tz = block_reduce_dd(acc_rz, lds);
     if (threadIdx.x == 0 && a.partA) {
         const int b = a.slotA + blockIdx.x, st = a.strideA;
-        const bool pub = FUSED && a.rec.enabled;
-        store_partial(a.partA + FA_PAP * st + b, tp.hi, pub); store_partial(a.partA + (FA_PAP + FA_LO) * st + b, tp.lo, pub);
-        store_partial(a.partA + FA_RZ * st + b, tz.hi, pub);  store_partial(a.partA + (FA_RZ + FA_LO) * st + b, tz.lo, pub);
+        a.partA[FA_PAP * st + b] = tp.hi; a.partA[(FA_PAP + FA_LO) * st + b] = tp.lo;
+        a.partA[FA_RZ * st + b] = tz.hi;  a.partA[(FA_RZ + FA_LO) * st + b] = tz.lo;
+        if (FUSED && a.fl.part) { const double v[FA_COUNT] = {tp.hi, tz.hi, tp.lo, tz.lo}; store_flagged(a.fl, b, FA_COUNT, v); }     // field order FA_*
     }
-    if (FUSED) arrive_and_record(0, a.partA, a.strideA, a.rec, lds);
 }
 
 // ---- flat update: state initialisation, resume step of the mixed-precision path, generic CSR path -----------------
@@ -1026,8 +1088,9 @@ struct UpdateStArgs {
     const CgState* s_in; CgState* s_out;
     int rule;
     int reverse;         // take the items from the last to the first (start where the stencil launch ended)
-    const int* stop_req; // single context: pinned host word, sampled once per iteration by block 0 -> CgState::stop (msg_solver.cpp:82-87); may be null
-    RecSpec rec;         // team: this launch ends the update phase -> its last block writes the part's record
+    const int* stop_req; // pinned host word, sampled once per iteration by block 0 -> CgState::stop (msg_solver.cpp:82-87) and, in a team, -> the
+                         // part's record (every part ORs its own sample with the other parts' records, so all decide alike); may be null
+    FlagSpec fl;         // team: every block also stores its partials flagged, for the reducer launch that runs beside this one
 };
 
 template <typename T, int VEC, int XM, bool HAS_U, int DEPTH, bool DESC>
@@ -1040,8 +1103,8 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const ItemSeq seq = item_seq(a.wl, wave);
     MI355CG_WT_BEGIN
-    // single context: the stop request (a pinned HOST word) is sampled once per iteration by block 0 -- a scalar load issued
-    // here and consumed in the epilogue, so its PCIe round trip runs under the whole launch
+    // the stop request (a pinned HOST word) is sampled once per iteration by block 0 -- a scalar load issued here and consumed
+    // in the epilogue, so its PCIe round trip runs under the whole launch
     int stop_word = 0;
     if (blockIdx.x == 0 && a.stop_req) stop_word = scalar_load(a.stop_req);
     constexpr bool FULL = XM == 1;
@@ -1116,9 +1179,28 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     StateLite s;
     if (a.src.mbox) {
         __shared__ double recs[kMaxRecDst * kRecWords];
+        const PreParts pre = prefetch_parts(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, 1);
+        PreParts pre_rz{0, 0, 0, 0};
+        if (FULL) pre_rz = prefetch_parts(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, 1);
         s = load_state_lite(a.s_in);
-        if (s.done) { if (blockIdx.x == 0 && threadIdx.x == 0) { copy_state(a.s_out, a.s_in); announce_only(a.rec); } return; }
-        if (!gather_records(a.src, recs)) { if (blockIdx.x == 0 && threadIdx.x == 0) { fail_transport(a.s_out, a.s_in); announce_only(a.rec); } return; }
+        if (s.done) {
+            if (threadIdx.x == 0) { store_flagged_zero(a.fl, a.slotB + blockIdx.x, FB_LL_COUNT); if (blockIdx.x == 0) copy_state(a.s_out, a.s_in); }
+            return;
+        }
+        {   // this part's own (Ap, p) [and (r, p)] from its partials, into its slot of the records
+            double* R = recs + a.src.me * kRecWords;
+            if (threadIdx.x < kRecWords) R[threadIdx.x] = 0.0;
+            const dd pap = reduce_parts_dd_pre(pre, a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, 1, lds);
+            dd rzd = dd_zero();
+            if (a.rule == 0) rzd = FULL ? reduce_parts_dd_pre(pre_rz, a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, 1, lds)
+                                        : reduce_parts_dd(a.partA + FA_RZ * a.strideA, a.partA + (FA_RZ + FA_LO) * a.strideA, a.nA, 1, lds);
+            __syncthreads();
+            if (threadIdx.x == 0) { R[FA_PAP] = pap.hi; R[FA_PAP + FA_LO] = pap.lo; R[FA_RZ] = rzd.hi; R[FA_RZ + FA_LO] = rzd.lo; }
+        }
+        if (!gather_records(a.src, recs)) {
+            if (threadIdx.x == 0) { store_flagged_zero(a.fl, a.slotB + blockIdx.x, FB_LL_COUNT); if (blockIdx.x == 0) fail_transport(a.s_out, a.s_in); }
+            return;
+        }
         alpha_from_records(s, a.rule, recs, a.src.world, &alpha_d, &rz);
     } else {
         const PreParts pre = prefetch_parts(a.partA + FA_PAP * a.strideA, a.partA + (FA_PAP + FA_LO) * a.strideA, a.nA, a.esA);
@@ -1221,12 +1303,14 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     if (FULL && HAS_U) { t_emax = block_reduce<true>(s_emax, lds); t_e2 = block_reduce_dd(s_e2, lds); }
     if (threadIdx.x == 0) {
         const int b = a.slotB + blockIdx.x, st = a.strideB;
-        const bool pub = a.rec.enabled != 0;
-        store_partial(a.partB + FB_RR * st + b, t_rr.hi, pub); store_partial(a.partB + (FB_RR + FB_LO) * st + b, t_rr.lo, pub);
-        store_partial(a.partB + FB_D2 * st + b, t_d2.hi, pub); store_partial(a.partB + (FB_D2 + FB_LO) * st + b, t_d2.lo, pub);
-        store_partial(a.partB + FB_E2 * st + b, t_e2.hi, pub); store_partial(a.partB + (FB_E2 + FB_LO) * st + b, t_e2.lo, pub);
-        store_partial(a.partB + FB_RMAX * st + b, t_rmax, pub); store_partial(a.partB + FB_DMAX * st + b, t_dmax, pub);
-        store_partial(a.partB + FB_EMAX * st + b, t_emax, pub);
+        a.partB[FB_RR * st + b] = t_rr.hi; a.partB[(FB_RR + FB_LO) * st + b] = t_rr.lo;
+        a.partB[FB_D2 * st + b] = t_d2.hi; a.partB[(FB_D2 + FB_LO) * st + b] = t_d2.lo;
+        a.partB[FB_E2 * st + b] = t_e2.hi; a.partB[(FB_E2 + FB_LO) * st + b] = t_e2.lo;
+        a.partB[FB_RMAX * st + b] = t_rmax; a.partB[FB_DMAX * st + b] = t_dmax; a.partB[FB_EMAX * st + b] = t_emax;
+        if (a.fl.part) {                                                  // field order FB_*, then the stop request this launch sampled
+            const double v[FB_LL_COUNT] = {t_rr.hi, t_d2.hi, t_e2.hi, t_rr.lo, t_d2.lo, t_e2.lo, t_rmax, t_dmax, t_emax, (blockIdx.x == 0 && stop_word) ? 1.0 : 0.0};
+            store_flagged(a.fl, b, FB_LL_COUNT, v);
+        }
         if (blockIdx.x == 0) {
             copy_state(a.s_out, a.s_in);
             CgState* o = a.s_out;
@@ -1234,7 +1318,6 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
             o->stop = stop_word != 0;              // the reference tests its flag once per iteration (msg_solver.cpp:82-87)
         }
     }
-    arrive_and_record(1, a.partB, a.strideB, a.rec, lds);
 }
 
 // ---- end-of-chunk check: same decision as the next stencil prologue, without advancing -------------
@@ -1254,8 +1337,9 @@ __global__ __launch_bounds__(kBlock) void k_check(const CheckArgs a) {
     Decision d;
     if (a.src.mbox) {
         __shared__ double recs[kMaxRecDst * kRecWords];
+        own_record_B(recs, a.src.me, a.partB, a.nB, a.strideB, 2, lds);
         if (!gather_records(a.src, recs)) { if (threadIdx.x == 0) fail_transport(a.summary, a.s_in); return; }
-        d = decide_from_records(s, a.rp, recs, a.src.world);
+        d = decide_from_records(s, a.rp, recs, a.src.world, true, true);
     } else d = reduce_and_decide(s, a.rp, a.partB, a.nB, a.strideB, a.esB, 1, lds);
     if (threadIdx.x == 0) write_state_after_decision(a.summary, a.hist, a.s_in, s, d);
 }

@@ -92,7 +92,6 @@ struct mi355cg_ctx {
     mi355cg_params dist_prm{};                    // slab mode: parameters given to mi355cg_dist_begin
     bool dist_active = false, is_slab = false;
     CgState *sA = nullptr, *sB = nullptr, *summary = nullptr;
-    unsigned* ticket = nullptr;         // arrival counter of the launch that writes a team record (RecSpec)
     int* stop_h = nullptr;              // pinned host word: a stop request, sampled by block 0 of every update launch (msg_solver.cpp:82-87)
     int* stop_dev = nullptr;            // the same word as the device addresses it (nullptr while no solve with a stop flag is running)
     HistEntry* hist = nullptr;
@@ -331,7 +330,7 @@ struct IterCfg { RuleParams rp; int want_diag; bool has_u; bool x2 = false; };
 
 // Phase A'.  Does NOT flip c->cur (a part's interior and edge launches share one direction pair).
 template <typename T, int VEC>
-void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[kRing], const Where& w, const PartSrc& pb, const RecSpec* rec = nullptr) {
+void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T* const p[kRing], const Where& w, const PartSrc& pb, const FlagSpec* fl = nullptr) {
     if (w.plan->wl.nitems == 0) return;
     StencilArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
@@ -340,7 +339,7 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
     a.partA = c->partA; a.strideA = c->strideA; a.slotA = w.slot;
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     a.store_ghosts = c->is_slab ? 1 : 0;
-    if (rec) a.rec = *rec;
+    if (fl) a.fl = *fl;
     const dim3 grid(w.plan->grid), block(kBlock);
     const bool msg = cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM, gc = c->has_gc, d3 = c->depth == 3;
 #define MI355CG_ST(MSG, D, GC) hipLaunchKernelGGL((k_stencil<T, VEC, true, MSG, D, true, GC>), grid, block, 0, w.stream, a)
@@ -356,7 +355,7 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
 // Phase B on the stencil's work items, marched the other way (it starts on what the stencil launch touched last).
 // c->cur was flipped after this iteration's stencil launch: it is the iteration number's parity.
 template <typename T, int VEC>
-void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* const p[kRing], const T* u, const Where& w, const PartSrc& pa, const RecSpec* rec = nullptr) {
+void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* const p[kRing], const T* u, const Where& w, const PartSrc& pa, const FlagSpec* fl = nullptr) {
     if (w.plan->wl.nitems == 0) return;
     UpdateStArgs<T> a{};
     a.g = kernel_geom<T, VEC>(c); a.wl = w.plan->wl;
@@ -365,8 +364,8 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
     a.partA = pa.ptr; a.nA = pa.n; a.strideA = pa.fstride; a.esA = pa.estride; a.src = pa.rec;
     a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slot;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
-    if (rec) a.rec = *rec;
-    else a.stop_req = c->stop_dev;                // single context: block 0 samples the pinned stop word every iteration (a team's travels in its records)
+    if (fl) a.fl = *fl;
+    a.stop_req = w.slot == 0 ? c->stop_dev : nullptr;   // block 0 samples the pinned stop word once per iteration (of a phase in two launches: the one that runs last and owns slot 0)
     const dim3 grid(w.plan->grid), block(kBlock);
     const bool d3 = c->depth == 3 && !(cfg.x2 && c->cur == 0 && c->xsteps == 8);
 #define MI355CG_UST(XM, HASU) do { if (d3) hipLaunchKernelGGL((k_update_st<T, VEC, XM, HASU, 3, true>), grid, block, 0, w.stream, a); \
@@ -821,7 +820,6 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     }
     hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
     hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
-    if (hipMalloc((void**)&c->ticket, sizeof(unsigned)) != hipSuccess || hipMemset(c->ticket, 0, sizeof(unsigned)) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "ticket allocation failed"); return cleanup(); }
     if (hipHostMalloc((void**)&c->stop_h, sizeof(int)) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "stop word allocation failed"); return cleanup(); }
     *c->stop_h = 0;
     // The zero-fills above run on the NULL stream and are asynchronous to the host; the context's own stream is
@@ -934,7 +932,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->p[2], c->p[3], c->p[4], c->p[5], c->p[6], c->p[7], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf,
                    c->pf[0], c->pf[1], c->pf[2], c->pf[3], c->pf[4], c->pf[5], c->pf[6], c->pf[7], c->apf,
-                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist, c->ticket};
+                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
     for (void* p : dev) if (p) hipFree(p);
     if (c->csr_row_map) hipFree(c->csr_row_map);
     if (c->csr_entries) hipFree(c->csr_entries);

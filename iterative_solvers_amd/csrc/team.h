@@ -202,7 +202,8 @@ struct TeamRecArgs {
     const int* stop_req;                          // pinned host word (update records only), may be null
     RecSpec rs;                                   // destinations, slot, stamp
 };
-// the record of the initialisation pass (a launch of its own: k_init_fresh is a flat kernel without an arrival ticket)
+// the record of the initialisation pass, from its plain partials (behind it on its stream: k_init_fresh is a flat kernel that
+// stores nothing flagged)
 __global__ __launch_bounds__(kBlock) void k_team_record(const TeamRecArgs a) {
     __shared__ double lds[2 * kWaves];
     __shared__ double rec[kRecWords];
@@ -275,9 +276,12 @@ struct TeamPart {
     std::vector<long long> recv_row_off;                  // PUSH halo: where row message i of recvs lands in the receive buffer (-1: a column message)
     ColArgs unpack_rows{};                                // PUSH halo: receive buffer -> ghost rows
     u64 **dst_self[2] = {nullptr, nullptr};               // device arrays for RecSpec::dst, per phase: own mailbox only (REC_RCCL) ...
-    u64 **dst_all[2] = {nullptr, nullptr};                // ... or every reachable part's
+    u64 **dst_all[2] = {nullptr, nullptr};                // ... or every OTHER reachable part's
     u64 **flag_all[2] = {nullptr, nullptr};               // RecSpec::flag, matching dst_all
     int ndst_all = 0;
+    u64* pll[2] = {nullptr, nullptr};                     // this part's flagged partials per phase (what its reducer launches poll)
+    hipStream_t side = nullptr;                           // the reducer launches of REC_MAILBOX run here, beside the producers
+    int nslots[2] = {0, 0};                               // partial slots the last phase of each kind wrote (what the next consumer reduces)
     std::vector<Seg> sends, recvs;                        // ordered by (peer, id)
     std::vector<long long> send_off, recv_off;            // column messages: offset in send_cols / recv_cols
     std::vector<int> halo_from, halo_to;                  // distinct neighbour ranks
@@ -375,7 +379,8 @@ void team_free(mi355cg_team_s* t) {
     for (auto& p : t->parts) {
         if (p.c) hipSetDevice(p.c->device);
         if (p.slab) ipc_pool().release(p.slab);
-        for (void* q : {(void*)p.send_cols, (void*)p.dst_self[0], (void*)p.dst_self[1], (void*)p.dst_all[0], (void*)p.dst_all[1],
+        if (p.side) { hipStreamSynchronize(p.side); hipStreamDestroy(p.side); }
+        for (void* q : {(void*)p.send_cols, (void*)p.pll[0], (void*)p.pll[1], (void*)p.dst_self[0], (void*)p.dst_self[1], (void*)p.dst_all[0], (void*)p.dst_all[1],
                         (void*)p.flag_all[0], (void*)p.flag_all[1]}) if (q) hipFree(q);
         for (hipEvent_t e : {p.ev_recA, p.ev_gA, p.ev_redge, p.ev_recB, p.ev_gB, p.ev_halo}) if (e) hipEventDestroy(e);
         if (p.comm) hipStreamDestroy(p.comm);
@@ -436,6 +441,13 @@ int team_finish_setup(mi355cg_team_s* t) {
         mi355cg_ctx* c = p.c;
         HIPCK(hipSetDevice(c->device));
         HIPCK(hipStreamCreateWithFlags(&p.comm, hipStreamNonBlocking));
+        HIPCK(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
+        if (c->strideA > kMaxPartSlots || c->strideB > kMaxPartSlots) return fail(MI355CG_ERR_INVALID, "a phase writes %d partial slots, the reducer takes %d", std::max(c->strideA, c->strideB), kMaxPartSlots);
+        for (int ph = 0; ph < 2; ++ph) {
+            const size_t words = (size_t)(ph == 0 ? c->strideA : c->strideB) * 2 * (ph == 0 ? FA_COUNT : FB_LL_COUNT);
+            HIPCK(hipExtMallocWithFlags((void**)&p.pll[ph], sizeof(u64) * words, hipDeviceMallocUncached));
+            HIPCK(hipMemset(p.pll[ph], 0, sizeof(u64) * words));
+        }
         const PartLists L = part_lists(t->segs, p.rank);
         if (int rc = ipc_pool().acquire(c->device, mbox_bytes(t->world) + sizeof(double) * std::max<long long>(L.recv_total, 1), &p.slab)) return rc;
         p.mbox = (u64*)p.slab;
@@ -495,7 +507,7 @@ int team_build_tables(mi355cg_team_s* t) {
             for (void* q : {(void*)p.dst_self[ph], (void*)p.dst_all[ph], (void*)p.flag_all[ph]}) if (q) hipFree(q);
             p.dst_self[ph] = p.dst_all[ph] = p.flag_all[ph] = nullptr;
             std::vector<u64*> self{p.mbox + ml.rec(ph, 0, p.rank)}, all, flags;
-            for (int j = 0; j < t->world; ++j) if (p.peer_mbox[j]) { all.push_back(p.peer_mbox[j] + ml.rec(ph, 0, p.rank)); flags.push_back(p.peer_mbox[j] + ml.flag(ph, p.rank)); }
+            for (int j = 0; j < t->world; ++j) if (p.peer_mbox[j] && j != p.rank) { all.push_back(p.peer_mbox[j] + ml.rec(ph, 0, p.rank)); flags.push_back(p.peer_mbox[j] + ml.flag(ph, p.rank)); }
             if (int rc = upload_ptrs(&p.dst_self[ph], self)) return rc;
             if (int rc = upload_ptrs(&p.dst_all[ph], all)) return rc;
             if (int rc = upload_ptrs(&p.flag_all[ph], flags)) return rc;
@@ -552,11 +564,10 @@ int team_abandon(mi355cg_team_s* t, const char* what) {
 }
 
 // ---- records ---------------------------------------------------------------------------------------------------------
-// the record a producer launch writes itself when it ends a phase (cg_kernels.h: arrive_and_record)
-RecSpec team_rec_spec(mi355cg_team_s* t, TeamPart& p, int which, int nslots, u64 seq) {
+// where the record of (which, seq) of part p goes
+RecSpec team_rec_spec(mi355cg_team_s* t, TeamPart& p, int which, u64 seq) {
     const MboxLayout ml{t->world};
     RecSpec rs{};
-    rs.enabled = 1; rs.nslots = nslots; rs.ticket = p.c->ticket; rs.stop_req = which == 1 ? t->stop_h : nullptr;
     const bool everywhere = t->rec_mode != REC_RCCL;
     rs.ndst = everywhere ? p.ndst_all : 1;
     rs.dst = everywhere ? p.dst_all[which] : p.dst_self[which];
@@ -565,30 +576,51 @@ RecSpec team_rec_spec(mi355cg_team_s* t, TeamPart& p, int which, int nslots, u64
     rs.seq = stamp_of(seq); rs.slot = (int)(seq & 1); rs.flag_value = seq;
     return rs;
 }
-// the same record from a separate one-block launch (after the initialisation pass)
+// what the producer launches of (which, seq) get: their blocks store the partials flagged as well -- when anybody outside the stream reads them
+FlagSpec team_flag_spec(mi355cg_team_s* t, TeamPart& p, int which, u64 seq) {
+    FlagSpec f{};
+    if (t->world > 1) { f.part = p.pll[which]; f.stamp = stamp_of(seq); }
+    return f;
+}
+// The reducer launch of (which, seq): flagged partials of part p -> its record in the other parts' mailboxes.  REC_MAILBOX: on the
+// part's side stream, BESIDE the producer launch (it polls the flagged words as they arrive; the producer carries no tail work and
+// the consumer launch behind it does not wait for this one).  REC_RCCL / REC_EVENTS: on the compute stream, behind the producer.
+void team_reduce(mi355cg_team_s* t, TeamPart& p, int which, int nslots, u64 seq) {
+    p.nslots[which] = nslots;
+    if (t->world == 1) return;                                    // nobody else: the consumers reduce their own partials, as on a single GPU
+    ReduceArgs a{};
+    a.part = p.pll[which]; a.nslots = nslots; a.which = which; a.stamp = stamp_of(seq); a.budget = t->budget_ticks;
+    a.rs = team_rec_spec(t, p, which, seq);
+    hipLaunchKernelGGL(k_reduce_ll, dim3(1), dim3(kBlock), 0, t->rec_mode == REC_MAILBOX ? p.side : p.c->stream, a);
+    if (t->rec_mode == REC_EVENTS) hipEventRecord(which == 0 ? p.ev_recA : p.ev_recB, p.c->stream);
+}
+// the record of the initialisation pass: a one-block launch behind it that reads its plain partials
 void team_record(mi355cg_team_s* t, TeamPart& p, int which, int nslots, u64 seq) {
     mi355cg_ctx* c = p.c;
+    p.nslots[which] = nslots;
+    if (t->world == 1) return;
     TeamRecArgs a{};
     if (which == 0) { a.part = c->partA; a.stride = c->strideA; a.nsum = kNumSumsA; a.lo_off = FA_LO; a.max_first = 0; a.nmax = 0; }
     else { a.part = c->partB; a.stride = c->strideB; a.nsum = kNumSumsB; a.lo_off = FB_LO; a.max_first = FB_RMAX; a.nmax = 3; }
     a.stop_req = nullptr;        // the record of the initialisation pass never carries a stop request: the first one that can is iteration 1's
     a.n = nslots;
-    a.rs = team_rec_spec(t, p, which, nslots, seq);
+    a.rs = team_rec_spec(t, p, which, seq);
     hipLaunchKernelGGL(k_team_record, dim3(1), dim3(kBlock), 0, c->stream, a);
     if (t->rec_mode == REC_EVENTS) hipEventRecord(which == 0 ? p.ev_recA : p.ev_recB, c->stream);
 }
-// where a consumer launch of part p finds the records of phase `which` with sequence number seq
+// where a consumer launch of part p finds the scalars of phase `which` with sequence number seq: its own partials + the other parts' records
 PartSrc team_gsrc(const mi355cg_team_s* t, TeamPart& p, int which, u64 seq) {
     const MboxLayout ml{t->world};
     PartSrc s{};
-    s.rec.mbox = p.mbox + ml.rec(which, (int)(seq & 1), 0); s.rec.world = t->world; s.rec.stamp = stamp_of(seq); s.rec.budget = t->budget_ticks;
+    s.ptr = which == 0 ? p.c->partA : p.c->partB; s.n = p.nslots[which]; s.fstride = which == 0 ? p.c->strideA : p.c->strideB; s.estride = 1;
+    s.rec.mbox = p.mbox + ml.rec(which, (int)(seq & 1), 0); s.rec.world = t->world; s.rec.me = p.rank; s.rec.stamp = stamp_of(seq); s.rec.budget = t->budget_ticks;
     return s;
 }
-// REC_MAILBOX + WAIT_STREAM: the compute stream itself waits until every part's record of (which, seq) has been announced
+// REC_MAILBOX + WAIT_STREAM: the compute stream itself waits until every OTHER part's record of (which, seq) has been announced
 int part_wait_records(mi355cg_team_s* t, TeamPart& p, int which, u64 seq) {
     if (t->rec_mode != REC_MAILBOX || t->wait_mode != WAIT_STREAM) return MI355CG_OK;
     const MboxLayout ml{t->world};
-    for (int j = 0; j < t->world; ++j) HIPCK(hipStreamWaitValue64(p.c->stream, p.mbox + ml.flag(which, j), seq, hipStreamWaitValueGte, ~0ull));
+    for (int j = 0; j < t->world; ++j) if (j != p.rank) HIPCK(hipStreamWaitValue64(p.c->stream, p.mbox + ml.flag(which, j), seq, hipStreamWaitValueGte, ~0ull));
     return MI355CG_OK;
 }
 
@@ -699,21 +731,22 @@ int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 s
         if (int rc = part_wait_halo(t, p, seqB)) return rc;
     }
     prof_begin(c, &e0);
+    const FlagSpec fl = team_flag_spec(t, p, 0, seq);
     if (p.split && t->split_phases) {
-        const RecSpec rs = team_rec_spec(t, p, 0, c->interior.grid + c->edge.grid, seq);
-        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 1, seqB));
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 1, seqB), &fl);
         prof_end(c, 0, e0);
         if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
         if (int rc = part_wait_halo(t, p, seqB)) return rc;
         prof_begin(c, &e0);
-        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 1, seqB), &rs);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 1, seqB), &fl);
+        prof_end(c, 0, e0);
+        team_reduce(t, p, 0, c->interior.grid + c->edge.grid, seq);
     } else {
-        const RecSpec rs = team_rec_spec(t, p, 0, c->whole.grid, seq);
-        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), team_gsrc(t, p, 1, seqB), &rs);
+        launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), team_gsrc(t, p, 1, seqB), &fl);
+        prof_end(c, 0, e0);
+        team_reduce(t, p, 0, c->whole.grid, seq);
     }
-    prof_end(c, 0, e0);
     c->cur = (c->cur + 1) % c->xsteps;
-    if (t->rec_mode == REC_EVENTS) HIPCK(hipEventRecord(p.ev_recA, c->stream));
     return MI355CG_OK;
 }
 // update phase: edge items first (split), so the halo of r is on its way while the interior is updated
@@ -723,26 +756,25 @@ int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 se
     const bool ev = halo_uses_events(t);
     if (int rc = part_wait_records(t, p, 0, seq)) return rc;
     prof_begin(c, &e0);
+    const FlagSpec fl = team_flag_spec(t, p, 1, seq);
     if (p.split && t->split_phases) {
-        const RecSpec rs = team_rec_spec(t, p, 1, c->interior.grid + c->edge.grid, seq);
-        const bool has_int = c->interior.wl.nitems > 0;
-        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 0, seq), has_int ? nullptr : &rs);
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 0, seq), &fl);
         if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
         prof_end(c, 1, e0);
         if (ev) HIPCK(hipEventRecord(p.ev_redge, c->stream));
         if (int rc = part_push_halo(t, p, seq)) return rc;
         prof_begin(c, &e0);
-        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 0, seq), &rs);
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 0, seq), &fl);
         prof_end(c, 1, e0);
+        team_reduce(t, p, 1, c->interior.grid + c->edge.grid, seq);
     } else {
-        const RecSpec rs = team_rec_spec(t, p, 1, c->whole.grid, seq);
-        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0, seq), &rs);
-        if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
+        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0, seq), &fl);
         prof_end(c, 1, e0);
+        team_reduce(t, p, 1, c->whole.grid, seq);
+        if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
         if (ev) HIPCK(hipEventRecord(p.ev_redge, c->stream));
         if (int rc = part_push_halo(t, p, seq)) return rc;
     }
-    if (t->rec_mode == REC_EVENTS) HIPCK(hipEventRecord(p.ev_recB, c->stream));
     HIPCK(hipGetLastError());
     return MI355CG_OK;
 }
@@ -923,6 +955,11 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         if (cfg.has_u) if (int rc = ensure_u_on_device(c)) return rc;
         c->events.reset(); c->ev_pairs[0].clear(); c->ev_pairs[1].clear(); p.comm_pairs.clear();
         c->profiling = t->profiling;
+        // Block 0 of every update launch samples the pinned stop word (as mi355cg_solve's do): the sample goes into the part's state, for
+        // its own next stencil prologue, and into its record, for the other parts'.  Every part ORs its own sample with the samples in the
+        // other parts' records, so all of them take the decision INTERRUPTED in the same iteration.
+        c->stop_dev = nullptr;
+        HIPCK(hipHostGetDevicePointer((void**)&c->stop_dev, t->stop_h, 0));
         // one pass over the owned range (mi355cg_solve does the same); the ghost cells of the first direction are zeroed too:
         // they still hold the neighbours' last direction of the previous solve
         HIPCK(hipMemsetAsync(c->p[0], 0, sizeof(double) * c->storage_len, c->stream));
@@ -1054,7 +1091,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     }
     for (auto& p : t->parts) {
         HIPCK(hipSetDevice(p.c->device));
-        for (hipStream_t st : {p.c->stream, p.comm}) {
+        for (hipStream_t st : {p.c->stream, p.comm, p.side}) {
             const int rc = bounded_sync(t, st, nullptr, t->timeout_s + 2e-8 * (double)t->budget_ticks);
             if (rc < 0) return team_abandon(t, "a part's stream did not drain after the last iteration");
             if (rc) return rc;

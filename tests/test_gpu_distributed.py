@@ -124,24 +124,47 @@ def test_slabs_over_gloo_msg_rule(halo):
     assert np.array_equal(np.array(r0["cbs"]), np.array(got1, dtype=float))
 
 
-def test_bench_distributed_leg_runs_under_torchrun_with_rccl():
-    """bench.py's N > 1 code path (RCCL process group, device-side all_gather of library-owned
-    records) launched the way the harness launches it, on the one GPU of this box."""
+def _bench_line(cmd, env):
     import json
     import subprocess
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def _check_bench_legs(j):
+    assert j["n_gpus"] == 1 and j["steps"] == 60 and j["value"] > 0 and j["scaling"] == "weak" and j["rccl_nranks"] == 1
+    assert set(j["legs"]) == {"rccl-inline", "mailbox+push", "rccl-stream"} and "notes" not in j
+    for name in ("rccl-inline", "mailbox+push", "rccl-stream"):
+        leg = j["legs"][name]
+        assert "error" not in leg, leg
+        assert leg["transport"]["transport"] == "rccl" and leg["transport"]["rccl_lib"].startswith("librccl")      # real RCCL, world 1
+        assert leg["phases_ms"]["kernels_ms"] > 0 and leg["phases_ms"]["wall_ms"] > 0 and leg["repeats"] >= 3
+        v = leg["verify_against_one_gpu"]                                # every leg's own cross-check against a single context
+        assert v["ok"] is True and v["iterations"] == 30 and v["bit_identical"] is True
+    assert j["legs"]["rccl-inline"]["transport"]["records"] == "rccl" and j["legs"]["mailbox+push"]["transport"]["records"] == "mailbox"
+    assert j["headline_leg"] in j["legs"] and j["value"] == j["legs"][j["headline_leg"]]["value"]
+
+
+def test_bench_legs_under_torchrun():
+    """bench.py's N > 1 code path launched the way the harness launches it (torchrun: every worker is the coordinator of its own
+    rank), on the one GPU of this box: every leg runs in fresh rank processes over real RCCL at world size 1."""
     env = dict(os.environ, MI355CG_BENCH_DIST="1", MI355CG_FORCE_COLLECTIVES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29871", os.path.join(ROOT, "bench.py"),
-           "--gpus", "1", "--steps", "60", "--warmup", "10", "--grid", "512"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
-    assert j["n_gpus"] == 1 and j["steps"] == 60 and j["value"] > 0 and j["scaling"] == "weak"
-    assert "native RCCL team" in j["config"]["parallelism"] and "note" not in j          # the native loop ran, not the fallback
-    assert j["phases_ms"]["kernels_ms"] > 0 and j["phases_ms"]["wall_ms"] > 0
-    v = j["verify_against_one_gpu"]                                  # the line's own cross-check against a single context
-    assert v["ok"] is True and v["iterations"] == 30 and v["rel_diff"] <= 1e-12
+           "--gpus", "1", "--steps", "60", "--warmup", "10", "--grid", "512", "--repeats", "3", "--legs", "rccl-inline,mailbox+push,rccl-stream"]
+    _check_bench_legs(_bench_line(cmd, env))
+
+
+def test_bench_legs_without_a_launcher():
+    """The same started as plain `python bench.py`: the coordinator starts the rank processes itself."""
+    env = dict(os.environ, MI355CG_BENCH_DIST="1", MI355CG_FORCE_COLLECTIVES="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "10", "--grid", "512", "--repeats", "3", "--legs", "rccl-inline,mailbox+push,rccl-stream"]
+    _check_bench_legs(_bench_line(cmd, env))
 
 
 def test_slab_handles_refuse_the_whole_grid_entry_points():

@@ -238,6 +238,51 @@ def test_stop_requested_from_the_first_callback_stops_at_iteration_one(isa, orac
     np.testing.assert_allclose(x, o.x, rtol=1e-13)              # x after exactly one step (alpha from a differently summed dot)
 
 
+def test_stop_request_from_another_thread_acts_at_the_next_iteration_not_at_the_next_poll(isa):
+    """The reference tests its flag at the top of EVERY iteration (msg_solver.cpp:82-87).  Here the host queues chunks of up to 500
+    iterations (65 ms at N = 4096), so the request has to be seen by the DEVICE: block 0 of every update launch samples a pinned word
+    the solving thread keeps in step with the caller's flag, and the next stencil prologue turns it into INTERRUPTED.  No callback
+    is involved: another thread raises the flag at an arbitrary moment and the solve is back a few milliseconds later (the rest of
+    the chunk returns in its prologues), in the middle of a chunk."""
+    import ctypes as C
+    import threading
+    import time
+    s = isa.MatrixFreeSystem(4096, 4096, 1.0, 2.0, 1.0, 2.0)
+    h = s._handle
+    p = isa.default_params(isa.RULE_REL_2NORM)
+    p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = 10 ** 6, 1, 0, 0, 500
+    h.solve(isa.default_params(isa.RULE_REL_2NORM))                       # warm-up
+    lags, its = [], []
+    for delay in (0.21, 0.33, 0.27):
+        stop = C.c_int(0)
+        t_set = []
+
+        def raiser():
+            time.sleep(delay)
+            t_set.append(time.perf_counter())
+            stop.value = 1
+        th = threading.Thread(target=raiser)
+        th.start()
+        res = h.solve(p, None, stop)
+        t_back = time.perf_counter()
+        th.join()
+        assert res.stop_reason == isa.StopCriterion.INTERRUPTED and not res.converged
+        assert 500 < res.iterations < 10 ** 5
+        lags.append(t_back - t_set[0])
+        its.append(res.iterations)
+    assert max(lags) < 0.02, lags                                         # a poll-granular stop would lag 32 ms on average, up to 65
+    assert any(i % 500 for i in its), its                                 # ... and end on a chunk boundary
+    # the solver object's own flag (MSGSolver::requestStop from another thread), MSG rule
+    g = isa.GridSystem(2048, 2048, 1.0, 2.0, 1.0, 2.0)
+    m = isa.MSGSolver(g, g.get_rhs(), 1e-30, 10 ** 6)
+    m.setPrecisionEps(-1.0); m.setResidualEps(-1.0); m.setExactErrorEps(-1.0)
+    th = threading.Thread(target=lambda: (time.sleep(0.3), m.requestStop()))
+    th.start()
+    m.solve(g.get_true_solution_vector())
+    th.join()
+    assert m.getStopReason() == isa.StopCriterion.INTERRUPTED and not m.hasConverged() and 100 < m.getIterations() < 10 ** 5
+
+
 def test_stop_reason_texts_are_the_references(isa):
     """solver/msg_solver.hpp:85-100, verbatim: the strings are part of SolverResults.stop_reason and of the report."""
     want = {0: "Достигнуто максимальное число итераций",
@@ -441,6 +486,33 @@ def test_config4_grid_against_the_oracle_with_exact_inner_products(isa, oracle):
     assert sol.getIterations() == k == ex.iterations
     assert (sol.last_results.r_norm2, sol.last_results.initial_r_norm2) == (ex.r_norm, ex.initial_r_norm)
     assert np.array_equal(xg, ex.x)
+
+
+def test_config5_grid_against_the_oracle(isa, oracle):
+    """N = 32768 (BASELINE config 5's grid: 805 240 833 unknowns, 6.4 GB per vector, 58 GB of vectors on the one GPU).  Against the
+    oracle with exact inner products: right-hand side, ||r0||, ||r|| and ALL of x after 2 CG iterations, bit for bit; against the oracle
+    proper (the reference's serial sums, matrix_free_system.cpp:364-366, 383-441): ||r|| within north_star's 1e-12 relative to ||b||.
+    test_gpu_team.py ties the 8-part teams of this size to the same single-GPU bits.  Costs ~2.5 minutes (two serial CPU solves of
+    two iterations each on 805 M unknowns, ~25 s per iteration) and ~70 GB of host memory."""
+    N = 32768
+    s = isa.MatrixFreeSystem(N, N, 1.0, 2.0, 1.0, 2.0)
+    og = oracle.OracleGrid(N, N)
+    assert s.size() == og.size == 805240833
+    b = og.rhs()
+    assert np.array_equal(s.get_rhs(), b)
+    k = 2
+    sol = isa.MatrixFreeSolver(s, b, 1e-30, k)
+    xg = sol.solve()
+    res = sol.last_results
+    with oracle.exact_dots():
+        ex = og.mf_solve(eps=1e-30, max_iterations=k)
+    assert sol.getIterations() == k == ex.iterations
+    assert (res.r_norm2, res.initial_r_norm2) == (ex.r_norm, ex.initial_r_norm)
+    assert np.array_equal(xg, ex.x)
+    del ex, xg
+    ref = og.mf_solve(eps=1e-30, max_iterations=k)                                   # the reference's own serial sums
+    assert abs(res.r_norm2 - ref.r_norm) <= 1e-12 * ref.initial_r_norm
+    assert abs(res.initial_r_norm2 - ref.initial_r_norm) <= 1e-12 * ref.initial_r_norm
 
 
 def test_fixed_iteration_mode_ignores_convergence(isa):

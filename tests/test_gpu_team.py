@@ -247,3 +247,37 @@ def test_random_decompositions_match_one_gpu():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_team_stop_request_from_another_thread_acts_inside_a_chunk(world):
+    """As test_stop_request_from_another_thread_acts_at_the_next_iteration_not_at_the_next_poll, on a team: every part's update
+    launch samples the pinned word, the sample travels in the part's record, and all parts end INTERRUPTED in the same iteration,
+    in the middle of a queued chunk."""
+    import threading
+    import time
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    t = Team.local(2050, world, 0)
+    p = _params(isa, 1, max_iterations=10 ** 6, fixed_iterations=1, use_true_solution=0, callback_every=0, sync_every=500)
+    t.solve(_params(isa, 1, max_iterations=50, fixed_iterations=1))
+    stop = C.c_int(0)
+    t_set = []
+
+    def raiser():
+        time.sleep(0.3)
+        t_set.append(time.perf_counter())
+        stop.value = 1
+    th = threading.Thread(target=raiser)
+    th.start()
+    res = t.solve(p, stop_flag=stop)
+    t_back = time.perf_counter()
+    th.join()
+    assert res.stop_reason == 4 and not res.converged and 100 < res.iterations < 10 ** 5
+    # (parts that share one GPU order their streams with events: the launches left in the chunk return at once, the events and copies
+    #  around them still run)
+    assert t_back - t_set[0] < (0.05 if world == 1 else 0.4)
+    r2 = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 5))       # and the team is as good as new
+    s1, r1, _ = _single(isa, 2050, 1, eps_rel=1e-8, max_iterations=10 ** 5)
+    assert (r2.iterations, r2.r_norm2) == (r1.iterations, r1.r_norm2)
+    t.close()

@@ -65,40 +65,46 @@ def _worker(rank, world, port, n, decomp, modes, outdir):
         import iterative_solvers_amd as isa
         from iterative_solvers_amd.distributed import Team
         torch.cuda.set_device(0)
+        step = "start"
         for mode in modes:
-            for k in KEYS:
-                os.environ.pop(k, None)
-            os.environ.update(MODES[mode])
-            t = Team.rccl(n, decomp, device=0)
-            d = t.describe()
-            out[f"{mode}/desc"] = np.array([d["records"], d["wait"], d["halo"], str(d["split"]), str(d["ipc"]), str(d["shared_device"]), str(d["rccl_nranks"]), d["rccl_lib"], d["ipc_note"]])
-            # (1) REL_2NORM to convergence
-            r = t.solve(_params(isa, 1, **REL))
-            out[f"{mode}/rel"] = np.array([r.iterations, r.converged, r.stop_reason, r.r_norm2, r.initial_r_norm2])
-            out[f"{mode}/x"] = t.vector(0)
-            out[f"{mode}/cs"] = np.array(t.checksum(1))
-            # (2) MSG rule; only rank 0 passes a callback (the chunk schedule must not depend on it)
-            cbs = []
-            r = t.solve(_params(isa, 0, **MSG), callback=(lambda *a: cbs.append(a)) if rank == 0 else None)
-            out[f"{mode}/msg"] = np.array([r.iterations, r.converged, r.stop_reason, r.final_residual_norm, r.final_precision])
-            out[f"{mode}/cbs"] = np.array(cbs, dtype=float).reshape(-1, 4)
-            out[f"{mode}/xm"] = t.vector(0)
-            # (3) a stop request raised by the LAST rank only, before the solve: every rank ends INTERRUPTED after the same iteration
-            stop = C.c_int(1 if rank == world - 1 else 0)
-            r = t.solve(_params(isa, 0, **MSG), stop_flag=stop if rank == world - 1 else None)
-            out[f"{mode}/stop0"] = np.array([r.iterations, r.converged, r.stop_reason])
-            # (4) ... and raised by rank 1 from ITS it = 1 callback, in the middle of the solve
-            stop = C.c_int(0)
-            if rank == 1:
-                r = t.solve(_params(isa, 0, **MSG), callback=lambda it, *a: stop.__setattr__("value", 1 if it >= 1 else 0), stop_flag=stop)
-            else:
-                r = t.solve(_params(isa, 0, **MSG))
-            out[f"{mode}/stop1"] = np.array([r.iterations, r.converged, r.stop_reason])
-            # (5) the team still solves after all that
-            r = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=37, fixed_iterations=1))
-            out[f"{mode}/fixed"] = np.array([r.iterations, r.r_norm2])
-            t.close()
-            dist.barrier()
+            try:
+                for k in KEYS:
+                    os.environ.pop(k, None)
+                os.environ.update(MODES[mode])
+                step = "create"
+                t = Team.rccl(n, decomp, device=0)
+                d = t.describe()
+                out[f"{mode}/desc"] = np.array([d["records"], d["wait"], d["halo"], str(d["split"]), str(d["ipc"]), str(d["shared_device"]), str(d["rccl_nranks"]), d["rccl_lib"], d["ipc_note"]])
+                step = "(1) REL_2NORM to convergence"
+                r = t.solve(_params(isa, 1, **REL))
+                out[f"{mode}/rel"] = np.array([r.iterations, r.converged, r.stop_reason, r.r_norm2, r.initial_r_norm2])
+                out[f"{mode}/x"] = t.vector(0)
+                out[f"{mode}/cs"] = np.array(t.checksum(1))
+                step = "(2) MSG rule; only rank 0 passes a callback (the chunk schedule must not depend on it)"
+                cbs = []
+                r = t.solve(_params(isa, 0, **MSG), callback=(lambda *a: cbs.append(a)) if rank == 0 else None)
+                out[f"{mode}/msg"] = np.array([r.iterations, r.converged, r.stop_reason, r.final_residual_norm, r.final_precision])
+                out[f"{mode}/cbs"] = np.array(cbs, dtype=float).reshape(-1, 4)
+                out[f"{mode}/xm"] = t.vector(0)
+                step = "(3) a stop request raised by the LAST rank only, before the solve: every rank ends INTERRUPTED after the same iteration"
+                stop = C.c_int(1 if rank == world - 1 else 0)
+                r = t.solve(_params(isa, 0, **MSG), stop_flag=stop if rank == world - 1 else None)
+                out[f"{mode}/stop0"] = np.array([r.iterations, r.converged, r.stop_reason])
+                step = "(4) ... and raised by rank 1 from ITS it = 1 callback, in the middle of the solve"
+                stop = C.c_int(0)
+                if rank == 1:
+                    r = t.solve(_params(isa, 0, **MSG), callback=lambda it, *a: stop.__setattr__("value", 1 if it >= 1 else 0), stop_flag=stop)
+                else:
+                    r = t.solve(_params(isa, 0, **MSG))
+                out[f"{mode}/stop1"] = np.array([r.iterations, r.converged, r.stop_reason])
+                step = "(5) the team still solves after all that"
+                r = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=37, fixed_iterations=1))
+                out[f"{mode}/fixed"] = np.array([r.iterations, r.r_norm2])
+                step = "close"
+                t.close()
+                dist.barrier()
+            except Exception as e:
+                raise RuntimeError(f"rank {rank}, mode {mode}, step {step}: {e}") from e
         np.savez(os.path.join(outdir, f"r{rank}.npz"), **out)
     finally:
         dist.destroy_process_group()
