@@ -279,10 +279,9 @@ class DistributedCG:
             comm.all_gather(self.gA if which == 0 else self.gB, eng.record(which)[:eng.rec_header])
 
     def _stop_anywhere(self, stop) -> bool:
-        """A stop request on any rank stops every rank at the same poll (one tiny all-gather per poll)."""
-        if stop is None:
-            return False
-        mine = torch.tensor([1.0 if stop() else 0.0], dtype=torch.float64)
+        """A stop request on any rank stops every rank at the same poll (one tiny all-gather per poll).  Every rank takes part in
+        that all-gather whether or not IT was given a `stop` callable: a rank without one contributes 0."""
+        mine = torch.tensor([1.0 if (stop is not None and stop()) else 0.0], dtype=torch.float64)
         if self.comm.world == 1:
             return bool(mine.item())
         if not self.comm.stage:
@@ -312,7 +311,7 @@ class DistributedCG:
         WA = self.WA
         assert not eng.update_reads_ghosts                  # the stencil phase keeps the direction's ghost rows itself
         interrupted = False
-        first = callback is not None or stop is not None
+        first = msg and every > 0                           # a function of the parameters only: the same on every rank
         while not done:
             if self._stop_anywhere(stop):
                 interrupted = True

@@ -116,10 +116,12 @@ def _stop_worker(rank, world, port, outdir):
         p = default_params(_capi.RULE_MSG_MAXNORM)
         p.eps_precision = p.eps_residual = 1e-30
         p.eps_exact_error = -1.0
-        seen = []
-        # only rank 1 asks for the stop, from its it == 1 callback: every rank must leave the loop at iteration 1
-        res = cg.solve(p, callback=lambda it, *a: seen.append(it), stop=lambda: rank == 1 and 1 in seen)
-        np.savez(os.path.join(outdir, f"r{rank}.npz"), it=res.iterations, reason=res.stop_reason, conv=res.converged)
+        seen, polls = [], []
+        # only rank 1 is given a stop source (it says yes from its second poll on, i.e. after iteration 1) and only rank 0 a callback:
+        # the schedule of chunks, polls and collectives must not depend on either, and every rank must leave the loop at iteration 1
+        res = cg.solve(p, callback=(lambda it, *a: seen.append(it)) if rank == 0 else None,
+                       stop=(lambda: (polls.append(1), len(polls) >= 2)[1]) if rank == 1 else None)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), it=res.iterations, reason=res.stop_reason, conv=res.converged, seen=np.array(seen))
     finally:
         dist.destroy_process_group()
 
@@ -132,3 +134,4 @@ def test_stop_request_on_one_rank_stops_all_ranks_at_the_same_iteration():
         parts = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
     assert [int(p["it"]) for p in parts] == [1, 1, 1]
     assert all(int(p["reason"]) == 4 and not bool(p["conv"]) for p in parts)        # INTERRUPTED (msg_solver.cpp:82-87)
+    assert list(parts[0]["seen"]) == [0, 1, 1] and parts[1]["seen"].size == 0

@@ -491,7 +491,7 @@ def test_config4_grid_against_the_oracle_with_exact_inner_products(isa, oracle):
 def test_config5_grid_against_the_oracle(isa, oracle):
     """N = 32768 (BASELINE config 5's grid: 805 240 833 unknowns, 6.4 GB per vector, 58 GB of vectors on the one GPU).  Against the
     oracle with exact inner products: right-hand side, ||r0||, ||r|| and ALL of x after 2 CG iterations, bit for bit; against the oracle
-    proper (the reference's serial sums, matrix_free_system.cpp:364-366, 383-441): ||r|| within north_star's 1e-12 relative to ||b||.
+    proper (the reference's serial sums, matrix_free_system.cpp:364-366, 383-441): ||r|| within 1e-11 * ||b|| (see below).
     test_gpu_team.py ties the 8-part teams of this size to the same single-GPU bits.  Costs ~2.5 minutes (two serial CPU solves of
     two iterations each on 805 M unknowns, ~25 s per iteration) and ~70 GB of host memory."""
     N = 32768
@@ -510,9 +510,13 @@ def test_config5_grid_against_the_oracle(isa, oracle):
     assert (res.r_norm2, res.initial_r_norm2) == (ex.r_norm, ex.initial_r_norm)
     assert np.array_equal(xg, ex.x)
     del ex, xg
-    ref = og.mf_solve(eps=1e-30, max_iterations=k)                                   # the reference's own serial sums
-    assert abs(res.r_norm2 - ref.r_norm) <= 1e-12 * ref.initial_r_norm
-    assert abs(res.initial_r_norm2 - ref.initial_r_norm) <= 1e-12 * ref.initial_r_norm
+    # The reference's own serial sums.  A serial fp64 sum of U = 8e8 terms is itself only good to ~sqrt(U) * 2^-53 = 3e-12 relative
+    # (U * 2^-53 = 9e-8 at worst), and two CG steps pass that on to ||r||: measured 2.7e-12 * ||b||.  So at THIS size north_star's
+    # 1e-12 is inside the reference's own rounding noise; the bound asserted is 1e-11 * ||b||, and the statement with content is the
+    # bit-for-bit one above.
+    ref = og.mf_solve(eps=1e-30, max_iterations=k)
+    assert abs(res.r_norm2 - ref.r_norm) <= 1e-11 * ref.initial_r_norm
+    assert abs(res.initial_r_norm2 - ref.initial_r_norm) <= 1e-11 * ref.initial_r_norm
 
 
 def test_fixed_iteration_mode_ignores_convergence(isa):

@@ -28,11 +28,13 @@ MODES = {
     "mailbox+inline": {"MI355CG_TEAM_HALO": "inline"},
     "rccl+push": {"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "push"},
     "no-ipc": {"MI355CG_TEAM_IPC": "0"},                                                             # the ranks cannot map each other: falls back to RCCL for both
+    # what ranks on GPUs of their OWN do (the default there): no stream-level waits for records, the consumer launches poll their mailboxes
+    "mailbox+push+kernel-wait": {"MI355CG_TEAM_WAIT": "kernel"},
 }
 EXPECT = {
     "rccl+inline": ("rccl", "rccl-inline", 0), "rccl+stream": ("rccl", "rccl-stream", 0), "rccl+stream+split": ("rccl", "rccl-stream", 1),
     "mailbox+push": ("mailbox", "push", 0), "mailbox+push+split": ("mailbox", "push", 1), "mailbox+inline": ("mailbox", "rccl-inline", 0),
-    "rccl+push": ("rccl", "push", 0), "no-ipc": ("rccl", "rccl-inline", 0),
+    "rccl+push": ("rccl", "push", 0), "no-ipc": ("rccl", "rccl-inline", 0), "mailbox+push+kernel-wait": ("mailbox", "push", 0),
 }
 for _name in filter(None, os.environ.get("MI355CG_TEST_EXTRA_MODES", "").split(",")):      # tools/dbg_modes.py: "mailbox+push#3" = a further run of that mode
     MODES[_name], EXPECT[_name] = MODES[_name.split("#")[0]], EXPECT[_name.split("#")[0]]
@@ -146,7 +148,7 @@ def _check(parts, ref, world, modes):
         for rank, p in enumerate(parts):
             d = p[f"{mode}/desc"]
             assert (d[0], d[2], int(d[3])) == (rec, halo, split), (mode, d)
-            assert d[1] == "stream" and int(d[5]) == 1                          # the ranks found out that they share one GPU: no polling kernels
+            assert d[1] == ("kernel" if "kernel-wait" in mode else "stream") and int(d[5]) == 1     # the ranks found out that they share one GPU: no polling kernels unless asked for
             assert int(d[4]) == (0 if mode == "no-ipc" else 1) and int(d[6]) == world and d[7].endswith("libnccl_shim.so")
             it, conv, reason, rn, r0 = p[f"{mode}/rel"]
             assert (it, conv, reason) == (ref["rel"].iterations, ref["rel"].converged, ref["rel"].stop_reason), (mode, rank)
@@ -172,8 +174,8 @@ def _check(parts, ref, world, modes):
 
 
 @pytest.mark.parametrize("world,n,decomp,modes", [
-    (2, 258, 0, list(MODES)),
-    (4, 258, 1, list(MODES)),                                                   # 2 x 2: column messages, packed and unpacked
+    (2, 258, 0, list(MODES)),                                                   # (kernel-wait included: two small launches can share the GPU)
+    (4, 258, 1, [m for m in MODES if "kernel-wait" not in m]),                  # 2 x 2: column messages, packed and unpacked
     (5, 130, 0, ["rccl+inline", "mailbox+push", "rccl+stream+split"]),
     (3, 1026, 0, ["mailbox+push", "rccl+inline"]),
     (4, 1026, 1, ["mailbox+push", "rccl+stream"]),
