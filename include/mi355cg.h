@@ -249,6 +249,9 @@ int  mi355cg_team_part(mi355cg_team t, int local_index, mi355cg_handle *part, in
  * this process's parts; checksum covers this process's parts.                                                           */
 int  mi355cg_team_get_vector(mi355cg_team t, int which, double *global_packed);
 int  mi355cg_team_checksum(mi355cg_team t, int which, double *out2);
+/* which: 2 right-hand side, 3 exact solution: every local part takes its entries of the caller's GLOBAL packed vector -- the b of
+ * Solver(a, b, ...) (solver/solver.hpp:33-39) and the true_solution of MSGSolver::solve (msg_solver.cpp:64-72) may be anything.   */
+int  mi355cg_team_set_vector(mi355cg_team t, int which, const double *global_packed);
 int  mi355cg_team_setup_on_device(mi355cg_team t);                     /* mi355cg_setup_on_device for every local part */
 int  mi355cg_team_set_profiling(mi355cg_team t, int enable);
 int  mi355cg_team_phase_times(mi355cg_team t, double *kernel_ms, double *comm_ms, double *wall_ms);   /* per iteration */

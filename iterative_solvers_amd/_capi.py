@@ -26,7 +26,7 @@ EXPORTS = [
     "mi355cg_dist_halo", "mi355cg_dist_halo_recv_counts",
     "mi355cg_create_part", "mi355cg_checksum", "mi355cg_decompose", "mi355cg_halo_plan",
     "mi355cg_team_create_local", "mi355cg_team_unique_id", "mi355cg_team_create_rccl", "mi355cg_team_destroy",
-    "mi355cg_team_solve", "mi355cg_team_info", "mi355cg_team_part", "mi355cg_team_get_vector", "mi355cg_team_checksum",
+    "mi355cg_team_solve", "mi355cg_team_info", "mi355cg_team_part", "mi355cg_team_get_vector", "mi355cg_team_set_vector", "mi355cg_team_checksum",
     "mi355cg_team_set_profiling", "mi355cg_team_phase_times", "mi355cg_team_describe", "mi355cg_setup_on_device", "mi355cg_team_setup_on_device", "mi355cg_debug_plan",
 ]
 DECOMP_ROWS, DECOMP_2D = 0, 1
@@ -146,6 +146,7 @@ def load():
     L.mi355cg_team_info.argtypes = [H, IP, IP, IP, LLP]
     L.mi355cg_team_part.argtypes = [H, C.c_int, C.POINTER(H), IP]
     L.mi355cg_team_get_vector.argtypes = [H, C.c_int, _DP]
+    L.mi355cg_team_set_vector.argtypes = [H, C.c_int, _DP]
     L.mi355cg_team_checksum.argtypes = [H, C.c_int, DBP]
     L.mi355cg_debug_plan.argtypes = [C.c_int] * 5 + [IP, IP, IP, IP, IP]
     L.mi355cg_setup_on_device.argtypes = [H]

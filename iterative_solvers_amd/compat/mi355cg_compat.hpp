@@ -331,11 +331,9 @@ public:
         mi355cg_results res;
         mi355cg_team team = a.context()->team;
         if (team) {
-            // the parts hold the grid's own right-hand side and exact solution; a foreign b or u needs the single-GPU path
-            std::vector<double> own(b.extent(0));
-            mi355cg_compat::check(mi355cg_get_rhs(h, own.data()));
-            for (size_t i = 0; i < own.size(); ++i)
-                if (own[i] != b(i)) throw std::invalid_argument("MSGSolver on a distributed grid: the right-hand side must be the grid's own");
+            // Solver(a, b, ...) takes any b (solver/solver.hpp:33-39) and solve() any true_solution: the parts take their entries
+            mi355cg_compat::check(mi355cg_team_set_vector(team, 2, b.data()));
+            if (true_solution.extent(0) > 0) mi355cg_compat::check(mi355cg_team_set_vector(team, 3, true_solution.data()));
             mi355cg_compat::check(mi355cg_team_solve(team, &p, &mi355cg_compat::iter_trampoline, &cb,
                                                      reinterpret_cast<const volatile int*>(&stop_requested), &res));
         } else

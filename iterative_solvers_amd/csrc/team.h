@@ -1409,6 +1409,25 @@ int mi355cg_team_get_vector(mi355cg_team t, int which, double* global_packed) {
     return MI355CG_OK;
 }
 
+// which: 2 right-hand side, 3 exact solution.  The caller's GLOBAL packed vector (length mi355cg_size) is cut up: every part this
+// process drives takes the entries it owns (the Solver(a, b, ...) constructor takes any b, solver/solver.hpp:33-39; MSGSolver::solve
+// any true_solution, msg_solver.cpp:64-72).  On an RCCL team every rank calls it with the same vector.
+int mi355cg_team_set_vector(mi355cg_team t, int which, const double* global_packed) {
+    if (!t || !global_packed) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (which != 2 && which != 3) return fail(MI355CG_ERR_INVALID, "vector %d cannot be set (2 right-hand side, 3 exact solution)", which);
+    for (auto& p : t->parts) {
+        mi355cg_ctx* c = p.c;
+        HIPCK(hipSetDevice(c->device));
+        std::vector<double> own(std::max<long long>(c->pk_len, 1));
+        const PackGeom& pg = c->pg;
+        long long i = 0;
+        for (int k = 0; k < pg.nb_rows; ++k, i += pg.wb) std::memcpy(own.data() + i, global_packed + packed_index(t->gp, pg.xb0, pg.yb0 + k), sizeof(double) * pg.wb);
+        for (int k = 0; k < pg.nu_rows; ++k, i += pg.wu) std::memcpy(own.data() + i, global_packed + packed_index(t->gp, pg.xu0, pg.yu0 + k), sizeof(double) * pg.wu);
+        if (int rc = which == 2 ? mi355cg_set_rhs(c, own.data()) : mi355cg_set_true_solution(c, own.data())) return rc;
+    }
+    return MI355CG_OK;
+}
+
 // out2[0] = sum of v, out2[1] = sum of v^2 over the cells of this process's parts (double-double inside, rounded once)
 int mi355cg_team_checksum(mi355cg_team t, int which, double* out2) {
     if (!t || !out2) return fail(MI355CG_ERR_INVALID, "null argument");

@@ -459,6 +459,13 @@ class Team:
         _capi.check(self._lib.mi355cg_team_get_vector(self._h, which, out))
         return out
 
+    def set_vector(self, which: int, v: np.ndarray):
+        """which: 2 right-hand side, 3 exact solution; v in global packed order (every rank of an RCCL team passes the same vector)."""
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        if v.size != self.size:
+            raise ValueError(f"expected {self.size} entries, got {v.size}")
+        _capi.check(self._lib.mi355cg_team_set_vector(self._h, which, v))
+
     def checksum(self, which: int):
         o = (C.c_double * 2)()
         _capi.check(self._lib.mi355cg_team_checksum(self._h, which, o))

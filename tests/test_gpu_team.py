@@ -281,3 +281,33 @@ def test_team_stop_request_from_another_thread_acts_inside_a_chunk(world):
     s1, r1, _ = _single(isa, 2050, 1, eps_rel=1e-8, max_iterations=10 ** 5)
     assert (r2.iterations, r2.r_norm2) == (r1.iterations, r1.r_norm2)
     t.close()
+
+
+@pytest.mark.parametrize("world,decomp", [(3, 0), (4, 1)])
+def test_team_takes_a_foreign_right_hand_side_and_true_solution(world, decomp):
+    """Solver(a, b, ...) takes ANY b (solver/solver.hpp:33-39) and MSGSolver::solve any true_solution (msg_solver.cpp:64-72): a team
+    cuts the caller's global vectors up among its parts (mi355cg_team_set_vector) and solves as the single context does with them."""
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    n = 258
+    s1 = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0)
+    rng = np.random.default_rng(7)
+    b = s1.get_rhs() * rng.uniform(0.5, 1.5, s1.size())
+    u = s1.get_true_solution_vector() + rng.uniform(-1e-3, 1e-3, s1.size())
+    kw = dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=1e-4, max_iterations=10 ** 5)
+    s1._handle.set_rhs(b)
+    s1._handle.set_true_solution(u)
+    cb1 = []
+    r1 = s1._handle.solve(_params(isa, 0, **kw), callback=lambda *a: cb1.append(a))
+    t = Team.local(n, world, decomp)
+    t.set_vector(2, b)
+    t.set_vector(3, u)
+    assert np.array_equal(t.vector(2), b) and np.array_equal(t.vector(3), u)
+    cbs = []
+    rt = t.solve(_params(isa, 0, **kw), callback=lambda *a: cbs.append(a))
+    assert (rt.iterations, rt.stop_reason, rt.final_residual_norm, rt.final_precision, rt.final_error_norm) == \
+           (r1.iterations, r1.stop_reason, r1.final_residual_norm, r1.final_precision, r1.final_error_norm)
+    assert cbs == cb1 and np.array_equal(t.vector(0), s1._handle.solution())
+    with pytest.raises(ValueError):
+        t.set_vector(2, b[:-1])
+    t.close()
