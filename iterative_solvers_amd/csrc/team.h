@@ -241,15 +241,31 @@ __global__ __launch_bounds__(kBlock) void k_cols(const ColArgs a) {
 // PUSH halo: this part's boundary rows / packed columns into the neighbours' receive buffers (their memory: a peer GPU's over
 // xGMI, mapped through IPC when the neighbour is another process).  Plain stores: the launch boundary publishes them, and the
 // stream-ordered flag write that follows tells the neighbour, whose stream then scatters them into its ghost cells.
-constexpr int kMaxPush = 8;
+constexpr int kMaxPush = 12, kMaxPushPeers = 6;
 struct PushSeg { const double* src; double* dst; int n; };
-struct PushArgs { PushSeg s[kMaxPush]; int ns; };
+struct PushArgs {
+    PushSeg s[kMaxPush]; int ns;
+    unsigned* ticket;                 // arrival counter of this launch's workgroups, 0 between launches
+    u64* flag[kMaxPushPeers]; int nflag; u64 flag_value;      // the neighbours' halo words: set by the LAST workgroup, after everybody's stores
+};
+// The announcement rides on the launch itself: every workgroup makes its stores visible at system scope (release fence), takes a
+// ticket, and the last one stores the sequence number into the neighbours' halo words -- one hop less than a stream-ordered
+// hipStreamWriteValue64 behind the launch (~2 us of blit launch on the path update -> neighbour's next stencil).
 __global__ __launch_bounds__(kBlock) void k_push(const PushArgs a) {
     for (int k = 0; k < a.ns; ++k) {
         PushSeg s = a.s[0];
 #pragma unroll
         for (int j = 1; j < kMaxPush; ++j) if (j == k) s = a.s[j];
         for (int i = blockIdx.x * kBlock + threadIdx.x; i < s.n; i += gridDim.x * kBlock) s.dst[i] = s.src[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (last) {
+            for (int f = 0; f < kMaxPushPeers; ++f) if (f < a.nflag) st_sys(a.flag[f], a.flag_value);
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -287,6 +303,7 @@ struct TeamPart {
     std::vector<int> halo_from, halo_to;                  // distinct neighbour ranks
     ColArgs pack{}, unpack{};
     PushArgs push{};
+    unsigned* push_ticket = nullptr;
     bool split = false;                                   // interior / edge launches (the part has neighbours)
     hipEvent_t ev_recA = nullptr, ev_gA = nullptr, ev_redge = nullptr, ev_recB = nullptr, ev_gB = nullptr, ev_halo = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> comm_pairs;     // profiling: event pairs on the comm stream
@@ -380,7 +397,7 @@ void team_free(mi355cg_team_s* t) {
         if (p.c) hipSetDevice(p.c->device);
         if (p.slab) ipc_pool().release(p.slab);
         if (p.side) { hipStreamSynchronize(p.side); hipStreamDestroy(p.side); }
-        for (void* q : {(void*)p.send_cols, (void*)p.pll[0], (void*)p.pll[1], (void*)p.dst_self[0], (void*)p.dst_self[1], (void*)p.dst_all[0], (void*)p.dst_all[1],
+        for (void* q : {(void*)p.send_cols, (void*)p.push_ticket, (void*)p.pll[0], (void*)p.pll[1], (void*)p.dst_self[0], (void*)p.dst_self[1], (void*)p.dst_all[0], (void*)p.dst_all[1],
                         (void*)p.flag_all[0], (void*)p.flag_all[1]}) if (q) hipFree(q);
         for (hipEvent_t e : {p.ev_recA, p.ev_gA, p.ev_redge, p.ev_recB, p.ev_gB, p.ev_halo}) if (e) hipEventDestroy(e);
         if (p.comm) hipStreamDestroy(p.comm);
@@ -442,6 +459,8 @@ int team_finish_setup(mi355cg_team_s* t) {
         HIPCK(hipSetDevice(c->device));
         HIPCK(hipStreamCreateWithFlags(&p.comm, hipStreamNonBlocking));
         HIPCK(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
+        HIPCK(hipMalloc((void**)&p.push_ticket, sizeof(unsigned)));
+        HIPCK(hipMemset(p.push_ticket, 0, sizeof(unsigned)));
         if (c->strideA > kMaxPartSlots || c->strideB > kMaxPartSlots) return fail(MI355CG_ERR_INVALID, "a phase writes %d partial slots, the reducer takes %d", std::max(c->strideA, c->strideB), kMaxPartSlots);
         for (int ph = 0; ph < 2; ++ph) {
             const size_t words = (size_t)(ph == 0 ? c->strideA : c->strideB) * 2 * (ph == 0 ? FA_COUNT : FB_LL_COUNT);
@@ -531,6 +550,12 @@ int team_build_tables(mi355cg_team_s* t) {
             p.push.s[p.push.ns++] = ps;
         }
         if (!reach) p.push.ns = -1;
+        p.push.ticket = p.push_ticket;
+        p.push.nflag = 0;
+        if (reach) for (int j : p.halo_to) {
+            if (p.push.nflag >= kMaxPushPeers) return fail(MI355CG_ERR_INVALID, "a part pushes its halo to at most %d neighbours", kMaxPushPeers);
+            p.push.flag[p.push.nflag++] = p.peer_mbox[j] + ml.halo(p.rank);
+        }
     }
     return MI355CG_OK;
 }
@@ -692,15 +717,17 @@ int team_exchange_halo(mi355cg_team_s* t, u64 seq) {
     for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_halo_in(t, p)) return rc; }      // p = destination
     return MI355CG_OK;
 }
-// HALO_PUSH, producer side: one launch stores this part's boundary cells into the neighbours' memory; the stream then tells each
-// neighbour (a stream-ordered 64-bit write into its mailbox: it executes after the launch has completed and published its stores)
+// HALO_PUSH, producer side: one launch stores this part's boundary cells into the neighbours' receive buffers and, when all of its
+// workgroups have released their stores, the sequence number into the neighbours' halo words
 int part_push_halo(mi355cg_team_s* t, TeamPart& p, u64 seq) {
     if (t->halo_mode != HALO_PUSH || p.sends.empty()) return MI355CG_OK;
     const MboxLayout ml{t->world};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.c->stream); }
-    hipLaunchKernelGGL(k_push, dim3(32), dim3(kBlock), 0, p.c->stream, p.push);
-    for (int j : p.halo_to) HIPCK(hipStreamWriteValue64(p.c->stream, p.peer_mbox[j] + ml.halo(p.rank), seq, 0));
+    PushArgs a = p.push;
+    a.flag_value = seq;
+    hipLaunchKernelGGL(k_push, dim3(32), dim3(kBlock), 0, p.c->stream, a);
+    (void)ml;
     if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.c->stream); p.comm_pairs.push_back({e0, e1}); } }
     return MI355CG_OK;
 }

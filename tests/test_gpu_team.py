@@ -311,3 +311,28 @@ def test_team_takes_a_foreign_right_hand_side_and_true_solution(world, decomp):
     with pytest.raises(ValueError):
         t.set_vector(2, b[:-1])
     t.close()
+
+
+@pytest.mark.parametrize("n,world,decomp", [(258, 4, 1), (130, 3, 0), (514, 8, 1)])
+def test_local_team_with_mailboxes_and_pushed_halo(n, world, decomp, monkeypatch):
+    """The rank-process transport's mechanisms inside ONE process: records through the parts' mailboxes with stream-level waits (parts that
+    share a GPU must not poll for each other in kernels) and the halo pushed into the neighbours' receive buffers.  Same bits."""
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    monkeypatch.setenv("MI355CG_TEAM_RECORDS", "mailbox")
+    monkeypatch.setenv("MI355CG_TEAM_HALO", "push")
+    kw = dict(eps_rel=1e-8, max_iterations=10 ** 5)
+    s1, r1, _ = _single(isa, n, 1, **kw)
+    t = Team.local(n, world, decomp)
+    d = t.describe()
+    assert (d["transport"], d["records"], d["wait"], d["halo"]) == ("local", "mailbox", "stream", "push")
+    rt = t.solve(_params(isa, 1, **kw))
+    assert (rt.iterations, rt.r_norm2, rt.initial_r_norm2) == (r1.iterations, r1.r_norm2, r1.initial_r_norm2)
+    assert np.array_equal(t.vector(0), s1._handle.solution())
+    kw = dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iterations=10 ** 5)
+    s0, r0, cb0 = _single(isa, n, 0, **kw)
+    cbs = []
+    rm = t.solve(_params(isa, 0, **kw), callback=lambda *a: cbs.append(a))
+    assert (rm.iterations, rm.stop_reason, rm.final_residual_norm, rm.final_precision) == (r0.iterations, r0.stop_reason, r0.final_residual_norm, r0.final_precision)
+    assert cbs == cb0 and np.array_equal(t.vector(0), s0._handle.solution())
+    t.close()
