@@ -221,9 +221,8 @@ __global__ __launch_bounds__(kBlock) void k_team_record(const TeamRecArgs a) {
     __syncthreads();
     publish_record(rec, a.rs);
 }
-// halo messages <-> buffers: gather a vector's columns into the send buffer / scatter the receive buffer into ghost columns
-// (a column is strided in storage) and -- PUSH halo only -- into ghost rows (a row message lands in the receive buffer there,
-// because that, not the residual vector, is what the neighbour has mapped)
+// column messages <-> buffers: gather a vector's columns into the send buffer / scatter the receive buffer into ghost columns (a
+// column is strided in storage; a row travels in place)
 constexpr int kMaxColSegs = 8;
 struct ColSeg { int x, y0, n, row; long long off; };     // row = 0: cells (x, y0 .. y0+n-1); row = 1: cells (x .. x+n-1, y0)
 struct ColArgs { Geom g; double* v; double* buf; ColSeg s[kMaxColSegs]; int ns, scatter; };
@@ -238,9 +237,8 @@ __global__ __launch_bounds__(kBlock) void k_cols(const ColArgs a) {
         }
     }
 }
-// PUSH halo: this part's boundary rows / packed columns into the neighbours' receive buffers (their memory: a peer GPU's over
-// xGMI, mapped through IPC when the neighbour is another process).  Plain stores: the launch boundary publishes them, and the
-// stream-ordered flag write that follows tells the neighbour, whose stream then scatters them into its ghost cells.
+// PUSH halo: this part's boundary rows straight into the neighbours' ghost rows and its packed columns into their receive
+// buffers (their memory: a peer GPU's over xGMI, mapped through IPC when the neighbour is another process).
 constexpr int kMaxPush = 12, kMaxPushPeers = 6;
 struct PushSeg { const double* src; double* dst; int n; };
 struct PushArgs {
@@ -280,17 +278,17 @@ struct TeamPart {
     mi355cg_ctx* c = nullptr;
     int rank = 0;
     hipStream_t comm = nullptr;
-    // What other parts write into lives in ONE slab of uncached memory from a per-process pool that is never handed back to HIP
-    // (IpcPool): [mailbox | receive buffer].  It is the only memory a rank exports through IPC.
+    // What other parts write into comes from a per-process pool that is never handed back to HIP (IpcPool): ONE slab of uncached
+    // memory [mailbox | column receive buffer], and -- rank processes -- the residual vector (its ghost rows).  Nothing else is exported.
     void* slab = nullptr;
     u64* mbox = nullptr;                                  // this part's mailbox (MboxLayout)
-    double* recv_cols = nullptr;                          // receive buffer: packed column messages, then (PUSH halo) the row messages
+    double* recv_cols = nullptr;                          // receive buffer of the packed column messages
     std::vector<u64*> peer_mbox;                          // [world]: part j's mailbox as this part's device addresses it (nullptr: not reachable)
     std::vector<double*> peer_cols;                       // [world]: part j's receive buffer, same
+    std::vector<double*> peer_r;                          // [world]: part j's residual vector (row messages go straight into its ghost rows), same
+    bool r_pooled = false;                                // the part's residual vector comes from the IPC pool (rank processes export it)
     std::vector<void*> ipc_opened;                        // mappings to close
     double* send_cols = nullptr;                          // packed column messages to send
-    std::vector<long long> recv_row_off;                  // PUSH halo: where row message i of recvs lands in the receive buffer (-1: a column message)
-    ColArgs unpack_rows{};                                // PUSH halo: receive buffer -> ghost rows
     u64 **dst_self[2] = {nullptr, nullptr};               // device arrays for RecSpec::dst, per phase: own mailbox only (REC_RCCL) ...
     u64 **dst_all[2] = {nullptr, nullptr};                // ... or every OTHER reachable part's
     u64 **flag_all[2] = {nullptr, nullptr};               // RecSpec::flag, matching dst_all
@@ -347,18 +345,19 @@ namespace {
 // and allocates again has been seen to hand out a handle that a peer resolves to the OLD memory (and hipIpcGetMemHandle to refuse
 // recycled hipMalloc memory) once a process has created and destroyed a few teams.  A slab keeps its handle for the life of the process.
 struct IpcPool {
-    struct Slab { void* ptr; size_t bytes; int device; bool in_use; };
+    struct Slab { void* ptr; size_t bytes; int device; bool uncached; bool in_use; };
     std::mutex mu;
     std::vector<Slab> slabs;
-    int acquire(int device, size_t bytes, void** out) {
+    // uncached: memory that is polled while peers write it (mailboxes, receive buffers); otherwise ordinary device memory (a vector)
+    int acquire(int device, size_t bytes, bool uncached, void** out) {
         bytes = (bytes + 65535) / 65536 * 65536;
         std::lock_guard<std::mutex> g(mu);
         Slab* hit = nullptr;
-        for (auto& s : slabs) if (!s.in_use && s.device == device && s.bytes >= bytes && (!hit || s.bytes < hit->bytes)) hit = &s;
+        for (auto& s : slabs) if (!s.in_use && s.device == device && s.uncached == uncached && s.bytes >= bytes && s.bytes <= bytes + bytes / 4 && (!hit || s.bytes < hit->bytes)) hit = &s;
         if (!hit) {
             void* p = nullptr;
-            HIPCK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
-            slabs.push_back(Slab{p, bytes, device, false});
+            if (uncached) HIPCK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached)); else HIPCK(hipMalloc(&p, bytes));
+            slabs.push_back(Slab{p, bytes, device, uncached, false});
             hit = &slabs.back();
         }
         hit->in_use = true;
@@ -396,6 +395,7 @@ void team_free(mi355cg_team_s* t) {
     for (auto& p : t->parts) {
         if (p.c) hipSetDevice(p.c->device);
         if (p.slab) ipc_pool().release(p.slab);
+        if (p.r_pooled && p.c) { ipc_pool().release(p.c->r); p.c->r = nullptr; }
         if (p.side) { hipStreamSynchronize(p.side); hipStreamDestroy(p.side); }
         for (void* q : {(void*)p.send_cols, (void*)p.push_ticket, (void*)p.pll[0], (void*)p.pll[1], (void*)p.dst_self[0], (void*)p.dst_self[1], (void*)p.dst_all[0], (void*)p.dst_all[1],
                         (void*)p.flag_all[0], (void*)p.flag_all[1]}) if (q) hipFree(q);
@@ -411,8 +411,8 @@ void team_free(mi355cg_team_s* t) {
 }
 
 // The ordered message lists of one part and the layout of its buffers: every rank can compute them for every part.
-// Receive buffer: the column messages packed back to back (recv_off), then the row messages (recv_row_off; used by the PUSH halo).
-struct PartLists { std::vector<Seg> sends, recvs; std::vector<long long> send_off, recv_off, recv_row_off; long long send_len = 0, recv_len = 0, recv_total = 0; };
+// Send / receive buffers: the column messages packed back to back (rows travel in place).
+struct PartLists { std::vector<Seg> sends, recvs; std::vector<long long> send_off, recv_off; long long send_len = 0, recv_len = 0; };
 PartLists part_lists(const std::vector<Seg>& segs, int rank) {
     PartLists L;
     for (auto& s : segs) { if (s.src == rank) L.sends.push_back(s); if (s.dst == rank) L.recvs.push_back(s); }
@@ -421,8 +421,6 @@ PartLists part_lists(const std::vector<Seg>& segs, int rank) {
     std::sort(L.recvs.begin(), L.recvs.end(), by_peer(false));
     for (auto& s : L.sends) { L.send_off.push_back(L.send_len); if (s.kind == 1) L.send_len += seg_count(s); }
     for (auto& s : L.recvs) { L.recv_off.push_back(L.recv_len); if (s.kind == 1) L.recv_len += seg_count(s); }
-    L.recv_total = (L.recv_len + 31) / 32 * 32;                       // rows start 256-byte aligned
-    for (auto& s : L.recvs) { L.recv_row_off.push_back(s.kind == 0 ? L.recv_total : -1); if (s.kind == 0) L.recv_total += (seg_count(s) + 31) / 32 * 32; }
     return L;
 }
 Geom part_geom(const GridParams& gp, const Box& bx) {
@@ -468,29 +466,23 @@ int team_finish_setup(mi355cg_team_s* t) {
             HIPCK(hipMemset(p.pll[ph], 0, sizeof(u64) * words));
         }
         const PartLists L = part_lists(t->segs, p.rank);
-        if (int rc = ipc_pool().acquire(c->device, mbox_bytes(t->world) + sizeof(double) * std::max<long long>(L.recv_total, 1), &p.slab)) return rc;
+        if (int rc = ipc_pool().acquire(c->device, mbox_bytes(t->world) + sizeof(double) * std::max<long long>(L.recv_len, 1), true, &p.slab)) return rc;
         p.mbox = (u64*)p.slab;
         p.recv_cols = (double*)((char*)p.slab + mbox_bytes(t->world));
         (void)ml;
         for (hipEvent_t* e : {&p.ev_recA, &p.ev_gA, &p.ev_redge, &p.ev_recB, &p.ev_gB, &p.ev_halo}) HIPCK(hipEventCreateWithFlags(e, ev_flags));
-        p.sends = L.sends; p.recvs = L.recvs; p.send_off = L.send_off; p.recv_off = L.recv_off; p.recv_row_off = L.recv_row_off;
+        p.sends = L.sends; p.recvs = L.recvs; p.send_off = L.send_off; p.recv_off = L.recv_off;
         p.split = !p.sends.empty() || !p.recvs.empty();
         for (auto& s : p.sends) if (p.halo_to.empty() || p.halo_to.back() != s.dst) p.halo_to.push_back(s.dst);
         for (auto& s : p.recvs) if (p.halo_from.empty() || p.halo_from.back() != s.src) p.halo_from.push_back(s.src);
         p.pack = ColArgs{}; p.unpack = ColArgs{};
         p.pack.g = c->g; p.unpack.g = c->g; p.unpack.scatter = 1;
-        p.unpack_rows = ColArgs{}; p.unpack_rows.g = c->g; p.unpack_rows.scatter = 1;
         for (size_t i = 0; i < p.sends.size(); ++i) if (p.sends[i].kind == 1) { if (p.pack.ns >= kMaxColSegs) return fail(MI355CG_ERR_INVALID, "too many column messages"); p.pack.s[p.pack.ns++] = ColSeg{p.sends[i].x0, p.sends[i].y0, (int)seg_count(p.sends[i]), 0, p.send_off[i]}; }
-        for (size_t i = 0; i < p.recvs.size(); ++i) {
-            const Seg& s = p.recvs[i];
-            ColArgs& u = s.kind == 1 ? p.unpack : p.unpack_rows;
-            if (u.ns >= kMaxColSegs) return fail(MI355CG_ERR_INVALID, "too many halo messages");
-            u.s[u.ns++] = s.kind == 1 ? ColSeg{s.x0, s.y0, (int)seg_count(s), 0, p.recv_off[i]} : ColSeg{s.x0, s.y0, (int)seg_count(s), 1, p.recv_row_off[i]};
-        }
+        for (size_t i = 0; i < p.recvs.size(); ++i) if (p.recvs[i].kind == 1) { if (p.unpack.ns >= kMaxColSegs) return fail(MI355CG_ERR_INVALID, "too many column messages"); p.unpack.s[p.unpack.ns++] = ColSeg{p.recvs[i].x0, p.recvs[i].y0, (int)seg_count(p.recvs[i]), 0, p.recv_off[i]}; }
         if (int rc = alloc_vec(&p.send_cols, std::max<long long>(L.send_len, 1))) return rc;
-        p.pack.buf = p.send_cols; p.unpack.buf = p.recv_cols; p.unpack_rows.buf = p.recv_cols;
-        p.peer_mbox.assign(t->world, nullptr); p.peer_cols.assign(t->world, nullptr);
-        p.peer_mbox[p.rank] = p.mbox; p.peer_cols[p.rank] = p.recv_cols;
+        p.pack.buf = p.send_cols; p.unpack.buf = p.recv_cols;
+        p.peer_mbox.assign(t->world, nullptr); p.peer_cols.assign(t->world, nullptr); p.peer_r.assign(t->world, nullptr);
+        p.peer_mbox[p.rank] = p.mbox; p.peer_cols[p.rank] = p.recv_cols; p.peer_r[p.rank] = c->r;
         HIPCK(hipDeviceSynchronize());
     }
     if (!t->rccl) {
@@ -508,7 +500,7 @@ int team_finish_setup(mi355cg_team_s* t) {
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCK(e);
             (void)hipGetLastError();
         }
-        for (auto& p : t->parts) for (auto& q : t->parts) { p.peer_mbox[q.rank] = q.mbox; p.peer_cols[q.rank] = q.recv_cols; }
+        for (auto& p : t->parts) for (auto& q : t->parts) { p.peer_mbox[q.rank] = q.mbox; p.peer_cols[q.rank] = q.recv_cols; p.peer_r[q.rank] = q.c->r; }
     }
     HIPCK(hipSetDevice(t->parts[0].c->device));
     HIPCK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
@@ -537,16 +529,19 @@ int team_build_tables(mi355cg_team_s* t) {
         bool reach = true;
         for (size_t i = 0; i < p.sends.size(); ++i) {
             const Seg& s = p.sends[i];
-            if (!p.peer_cols[s.dst]) { reach = false; break; }
+            if (!p.peer_cols[s.dst] || !p.peer_r[s.dst]) { reach = false; break; }
             if (p.push.ns >= kMaxPush) return fail(MI355CG_ERR_INVALID, "too many halo messages for one push launch");
             PushSeg ps{};
             ps.n = (int)seg_count(s);
-            const PartLists Lq = part_lists(t->segs, s.dst);               // where the receiver expects this message in ITS receive buffer
-            long long off = -1;
-            for (size_t j = 0; j < Lq.recvs.size(); ++j) if (Lq.recvs[j].id == s.id) off = s.kind == 0 ? Lq.recv_row_off[j] : Lq.recv_off[j];
-            if (off < 0) return fail(MI355CG_ERR_STATE, "halo message %d has no receiver", s.id);
-            ps.src = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.send_cols + p.send_off[i];
-            ps.dst = p.peer_cols[s.dst] + off;
+            if (s.kind == 0) {                                             // a row: straight into the neighbour's ghost row
+                ps.src = seg_ptr(p.c, p.c->r, s); ps.dst = seg_ptr_g(t->geoms[s.dst], p.peer_r[s.dst], s);
+            } else {                                                       // a column: packed, into the neighbour's receive buffer where IT expects the message
+                const PartLists Lq = part_lists(t->segs, s.dst);
+                long long off = -1;
+                for (size_t j = 0; j < Lq.recvs.size(); ++j) if (Lq.recvs[j].id == s.id) off = Lq.recv_off[j];
+                if (off < 0) return fail(MI355CG_ERR_STATE, "halo message %d has no receiver", s.id);
+                ps.src = p.send_cols + p.send_off[i]; ps.dst = p.peer_cols[s.dst] + off;
+            }
             p.push.s[p.push.ns++] = ps;
         }
         if (!reach) p.push.ns = -1;
@@ -717,8 +712,8 @@ int team_exchange_halo(mi355cg_team_s* t, u64 seq) {
     for (auto& p : t->parts) { HIPCK(hipSetDevice(p.c->device)); if (int rc = part_halo_in(t, p)) return rc; }      // p = destination
     return MI355CG_OK;
 }
-// HALO_PUSH, producer side: one launch stores this part's boundary cells into the neighbours' receive buffers and, when all of its
-// workgroups have released their stores, the sequence number into the neighbours' halo words
+// HALO_PUSH, producer side: one launch stores this part's boundary cells into the neighbours' ghost rows / receive buffers and, when
+// all of its workgroups have released their stores, the sequence number into the neighbours' halo words
 int part_push_halo(mi355cg_team_s* t, TeamPart& p, u64 seq) {
     if (t->halo_mode != HALO_PUSH || p.sends.empty()) return MI355CG_OK;
     const MboxLayout ml{t->world};
@@ -736,11 +731,8 @@ int part_wait_halo(mi355cg_team_s* t, TeamPart& p, u64 seq) {
     if (t->halo_mode != HALO_PUSH || p.recvs.empty()) return MI355CG_OK;
     const MboxLayout ml{t->world};
     for (int j : p.halo_from) HIPCK(hipStreamWaitValue64(p.c->stream, p.mbox + ml.halo(j), seq, hipStreamWaitValueGte, ~0ull));
-    // one launch scatters everything that arrived: row messages into the ghost rows, column messages into the ghost columns
-    ColArgs a = p.unpack_rows; a.v = p.c->r;
-    for (int k = 0; k < p.unpack.ns && a.ns < kMaxColSegs; ++k) a.s[a.ns++] = p.unpack.s[k];
-    if (a.ns < p.unpack_rows.ns + p.unpack.ns) return fail(MI355CG_ERR_INVALID, "too many halo messages for one scatter launch");
-    if (a.ns) hipLaunchKernelGGL(k_cols, dim3(32), dim3(kBlock), 0, p.c->stream, a);
+    // row messages are in the ghost rows already; column messages wait in the receive buffer
+    if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, p.c->stream, a); }
     return MI355CG_OK;
 }
 bool halo_uses_events(const mi355cg_team_s* t) { return t->halo_mode == HALO_LOCAL || t->halo_mode == HALO_RCCL_STREAM; }
@@ -1267,7 +1259,7 @@ int mi355cg_team_unique_id(void* id128) {
 namespace {
 // What every rank tells the others at team creation: IPC handles of the three allocations its neighbours write into, and the
 // physical GPU it sits on.
-struct BootRec { hipIpcMemHandle_t slab; char bus[32]; int ok, pad; unsigned long long nonce; };
+struct BootRec { hipIpcMemHandle_t slab, r; char bus[32]; int ok, pad; unsigned long long nonce; };
 // all-gather of `bytes` per rank through the team's communicator (host buffers; staged through device memory)
 int boot_all_gather(mi355cg_team_s* t, const void* mine, void* all, size_t bytes) {
     TeamPart& p = t->parts[0];
@@ -1295,13 +1287,16 @@ int team_map_peers(mi355cg_team_s* t) {
     mine.ok = env_int("MI355CG_TEAM_IPC", 1) != 0 ? 1 : 0;
     if (!mine.ok) std::snprintf(why, sizeof why, "MI355CG_TEAM_IPC=0");
     if (mine.ok) {
-        const hipError_t e = hipIpcGetMemHandle(&mine.slab, p.slab);
+        hipError_t e = hipIpcGetMemHandle(&mine.slab, p.slab);
+        if (e == hipSuccess) e = p.r_pooled ? hipIpcGetMemHandle(&mine.r, p.c->r) : hipErrorInvalidValue;
         if (e != hipSuccess) { mine.ok = 0; std::snprintf(why, sizeof why, "hipIpcGetMemHandle: %s", hipGetErrorString(e)); (void)hipGetLastError(); }
     }
     // a word only this rank could have written (in a cell nothing reads before the first solve writes it)
     const unsigned long long nonce = ((unsigned long long)getpid() << 32) ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((unsigned long long)p.rank << 56);
     mine.nonce = nonce;
+    const double nonce_d = __builtin_bit_cast(double, (nonce & 0x000fffffffffffffull) | 0x3ff0000000000000ull);      // the same bits as a finite double, for the vector
     HIPCK(hipMemcpy(p.mbox + ml.halo(p.rank), &nonce, sizeof nonce, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(p.c->r, &nonce_d, sizeof nonce_d, hipMemcpyHostToDevice));          // (first cell of the lower ghost / boundary row: zeroed again below)
     if (hipDeviceGetPCIBusId(mine.bus, sizeof mine.bus, p.c->device) != hipSuccess) { std::snprintf(mine.bus, sizeof mine.bus, "rank%d", p.rank); (void)hipGetLastError(); }
     std::vector<BootRec> all(W);
     if (int rc = boot_all_gather(t, &mine, all.data(), sizeof(BootRec))) return rc;
@@ -1311,13 +1306,16 @@ int team_map_peers(mi355cg_team_s* t) {
     int opened = every ? 1 : 0;
     if (every) for (int j = 0; j < W && opened; ++j) {
         if (j == p.rank) continue;
-        void* ps = nullptr;
-        const hipError_t e = hipIpcOpenMemHandle(&ps, all[j].slab, hipIpcMemLazyEnablePeerAccess);
+        void *ps = nullptr, *pr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ps, all[j].slab, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) { p.ipc_opened.push_back(ps); e = hipIpcOpenMemHandle(&pr, all[j].r, hipIpcMemLazyEnablePeerAccess); }
         if (e != hipSuccess) { opened = 0; std::snprintf(why, sizeof why, "hipIpcOpenMemHandle(rank %d): %s", j, hipGetErrorString(e)); (void)hipGetLastError(); continue; }
-        p.ipc_opened.push_back(ps);
-        p.peer_mbox[j] = (u64*)ps; p.peer_cols[j] = (double*)((char*)ps + mbox_bytes(W));
-        unsigned long long seen = 0;                                   // does the mapping show what rank j wrote?
-        if (hipMemcpy(&seen, p.peer_mbox[j] + ml.halo(j), sizeof seen, hipMemcpyDeviceToHost) != hipSuccess || seen != all[j].nonce) {
+        p.ipc_opened.push_back(pr);
+        p.peer_mbox[j] = (u64*)ps; p.peer_cols[j] = (double*)((char*)ps + mbox_bytes(W)); p.peer_r[j] = (double*)pr;
+        unsigned long long seen = 0; double seen_d = 0;                // do the mappings show what rank j wrote?
+        const double want_d = __builtin_bit_cast(double, (all[j].nonce & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+        if (hipMemcpy(&seen, p.peer_mbox[j] + ml.halo(j), sizeof seen, hipMemcpyDeviceToHost) != hipSuccess || seen != all[j].nonce ||
+            hipMemcpy(&seen_d, p.peer_r[j], sizeof seen_d, hipMemcpyDeviceToHost) != hipSuccess || seen_d != want_d) {
             opened = 0; std::snprintf(why, sizeof why, "the mapping of rank %d's memory does not show what rank %d wrote (stale IPC mapping)", j, j); (void)hipGetLastError();
         }
     }
@@ -1327,10 +1325,11 @@ int team_map_peers(mi355cg_team_s* t) {
     for (int v : oks) if (!v) t->ipc_ok = false;
     const unsigned long long zero = 0;
     HIPCK(hipMemcpy(p.mbox + ml.halo(p.rank), &zero, sizeof zero, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(p.c->r, &zero, sizeof zero, hipMemcpyHostToDevice));
     if (!t->ipc_ok) {
         for (void* q : p.ipc_opened) hipIpcCloseMemHandle(q);
         p.ipc_opened.clear();
-        for (int j = 0; j < W; ++j) if (j != p.rank) { p.peer_mbox[j] = nullptr; p.peer_cols[j] = nullptr; }
+        for (int j = 0; j < W; ++j) if (j != p.rank) { p.peer_mbox[j] = nullptr; p.peer_cols[j] = nullptr; p.peer_r[j] = nullptr; }
         (void)hipGetLastError();
         t->ipc_note = why[0] ? why : "another rank could not map its peers";
         for (auto& ch : t->ipc_note) if (ch == ' ') ch = '_';
@@ -1354,6 +1353,13 @@ int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double
     TeamPart p; p.rank = rank;
     int rc = create_impl(n, m, a, b, c_, d, MI355CG_F64, device, bx.y_lo, bx.y_hi, bx.s_lo, bx.s_hi, world > 1, &p.c);
     if (rc) { team_free(t); return rc; }
+    if (world > 1) {
+        // the residual vector is what the neighbours' push launches write into: it has to come from the pool (see IpcPool)
+        void* pooled = nullptr;
+        if ((rc = ipc_pool().acquire(device, sizeof(double) * p.c->storage_len, false, &pooled))) { mi355cg_destroy(p.c); team_free(t); return rc; }
+        hipFree(p.c->r);
+        p.c->r = (double*)pooled; p.r_pooled = true;
+    }
     t->parts.push_back(p);
     if ((rc = team_finish_setup(t))) { team_free(t); return rc; }
     ncclUniqueId id;
