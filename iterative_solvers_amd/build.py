@@ -15,7 +15,10 @@ LIB_PATH = os.path.join(PKG_DIR, "libmi355cg.so")
 SOURCES = ["mi355cg.hip", "grid_setup.cpp"]
 HEADERS = ["cg_kernels.h", "csr_kernels.h", "team.h", "grid_setup.h", os.path.join("..", "..", "include", "mi355cg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-Wno-unused-value", "-Wno-unused-result", "-pthread"]
+         "-Wno-unused-value", "-Wno-unused-result", "-pthread",
+         # a one-lane atomic stays a one-lane atomic: the optimizer's wave-aggregated form reads its result back at once, which drains
+         # the load pipeline of the row-marching kernels at every item of the dynamic queues (cg_kernels.h: QueueSpec)
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _hipcc() -> str:

@@ -549,6 +549,28 @@ __device__ inline void fail_transport(CgState* out, const CgState* in) {
     out->done = 1; out->reason = kReasonTransport; out->converged = 0;
 }
 
+// ---- dynamic item queues (MI355CG_DYN_ROWS; experimental, see profiles/r03_tune_notes.md section 5) ------------------
+// With one tall item per wave a launch ends when its SLOWEST wave ends.  Queues even that out: the items are cut shorter, every
+// wave starts on its static first item and then takes tickets from a counter of its group (XCD class x 8 sub-groups: one address
+// sustains only ~20 M atomics/s); ticket t of sub-group g is item begin + W + 8 t + g of the class's range, so the groups sweep
+// the class's band together.  The ticket is asked for when an item is ENTERED and used at the next switch.  The counters of a
+// launch kind are zeroed by the launches of the other kind, which run between two of its launches.
+constexpr int kQueueSubs = 8;
+constexpr int kQueuePitch = 64;        // ints between two counters: every counter has a 256-B line (an L2 channel) of its own
+struct QueueSpec {
+    int* mine;            // kXcds * kQueueSubs counters of this launch kind, 0 at launch; nullptr: static round-robin (w, w + W, ...)
+    int* other;           // the other kind's counters, zeroed by this launch (may be null)
+};
+// lane 0 takes a ticket; the result stays in lane 0's register until the next item switch (the compiler waits for it there with a
+// counted vmcnt: by then it is an old operation).  Built with -amdgpu-atomic-optimizer-strategy=None (build.py): hipcc's atomic
+// optimizer would rewrite the one-lane atomic into its wave-aggregated form, which reads the result back at once -- a drain of the
+// rows in flight at every item.
+__device__ inline int queue_take(int* q, int lane) {
+    int v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
 // ---- phase A': fused direction update + 5-point stencil + dots ------------------------------------
 template <typename T>
 struct StencilArgs {
@@ -568,6 +590,7 @@ struct StencilArgs {
     int store_ghosts;    // part of a decomposed grid: also store p_new of the ghost rows (recomputed from the local ghost copies
                          // of r and p_old, bit-identical to the neighbour's rows), so the direction never has to cross ranks
     FlagSpec fl;         // team: every block also stores its partials flagged, for the reducer launch that runs beside this one
+    QueueSpec dq;        // dynamic item queues (see QueueSpec)
 };
 
 template <typename T, int VEC> struct VecOf { typedef T type __attribute__((ext_vector_type(VEC))); };
@@ -717,7 +740,12 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     ItemAddr F{};
     int f_idx = 0, f_so = 0, f_y = 0;
     rsrc_t rs_p = make_rsrc(a.pin), rs_r = make_rsrc(a.pin);
+    const int dq_nsub = min(kQueueSubs, (int)(gridDim.x / kXcds)), dq_sub = (int)(blockIdx.x / kXcds) % dq_nsub;      // (every sub-group has a workgroup)
+    int* const dq = a.dq.mine ? a.dq.mine + ((int)(blockIdx.x % kXcds) * kQueueSubs + dq_sub) * kQueuePitch : nullptr;
+    if (a.dq.other && blockIdx.x == 0 && threadIdx.x < kXcds * kQueueSubs) a.dq.other[threadIdx.x * kQueuePitch] = 0;
+    int dq_ticket = 0;                                          // lane 0: this wave's next ticket of its group's queue
     auto enter = [&](int item) {
+        if (dq) dq_ticket = queue_take(dq, lane);               // asked for now, needed at the next switch
         F = item_addr<T, VEC, false>(g, decode_item(a.wl, item), lane);
         rs_p = make_rsrc(a.pin + F.base_el);
         rs_r = make_rsrc(FUSED ? a.r + F.base_el : a.pin + F.base_el);
@@ -725,7 +753,8 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     };
     auto fetch = [&]() -> Raw {
         if (f_have && f_idx > F.nrows) {                         // lazily: the compute cursor may still need F (see promote)
-            f_item += seq.step; f_have = f_item < seq.end;
+            f_item = dq ? seq.begin + seq.step + __builtin_amdgcn_readfirstlane(dq_ticket) * dq_nsub + dq_sub : f_item + seq.step;
+            f_have = f_item < seq.end;
             if (f_have) enter(f_item);
         }
         const bool own = f_idx >= 0 && f_idx < F.nrows;
@@ -743,7 +772,6 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
     };
 
     // ---- compute cursor ----
-    int c_item = f_item;
     bool c_have = f_have;
     ItemAddr C{};
     int c_idx = -1, c_so = 0, c_y = 0, c_ve_gc = kOob;
@@ -873,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void k_stencil(const StencilArgs<T> a) {
                 }
                 if (c_idx == C.nrows) {                            // that was the halo row ahead of the last own row
                     if (FUSED && a.store_ghosts && is_ghost(c_y)) buf_store(pn, rs_po, C.vo_last, c_so);
-                    c_item += seq.step; c_have = c_item < seq.end;
+                    c_have = f_have;                          // the next item is the one the fetch cursor is in by now (1 .. DEPTH rows into it), if any
                     if (c_have) promote();
                 } else ++c_idx;
             }
@@ -1091,6 +1119,7 @@ struct UpdateStArgs {
     const int* stop_req; // pinned host word, sampled once per iteration by block 0 -> CgState::stop (msg_solver.cpp:82-87) and, in a team, -> the
                          // part's record (every part ORs its own sample with the other parts' records, so all decide alike); may be null
     FlagSpec fl;         // team: every block also stores its partials flagged, for the reducer launch that runs beside this one
+    QueueSpec dq;        // dynamic item queues (see QueueSpec)
 };
 
 template <typename T, int VEC, int XM, bool HAS_U, int DEPTH, bool DESC>
@@ -1118,7 +1147,12 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     int f_idx = 0, f_so = 0, f_y = 0;
     rsrc_t rs_p = make_rsrc(a.p), rs_r = rs_p, rs_x = rs_p, rs_u = rs_p;
     rsrc_t rs_pp[NP > 0 ? NP : 1] = {rs_p};
+    const int dq_nsub = min(kQueueSubs, (int)(gridDim.x / kXcds)), dq_sub = (int)(blockIdx.x / kXcds) % dq_nsub;      // (every sub-group has a workgroup)
+    int* const dq = a.dq.mine ? a.dq.mine + ((int)(blockIdx.x % kXcds) * kQueueSubs + dq_sub) * kQueuePitch : nullptr;
+    if (a.dq.other && blockIdx.x == 0 && threadIdx.x < kXcds * kQueueSubs) a.dq.other[threadIdx.x * kQueuePitch] = 0;
+    int dq_ticket = 0;
     auto enter = [&](int idx) {
+        if (dq) dq_ticket = queue_take(dq, lane);
         F = item_addr<T, VEC, DESC>(g, decode_item(a.wl, a.reverse ? seq.end - 1 - (idx - seq.begin) : idx), lane);   // reversed within the wave's class
         rs_p = make_rsrc(a.p + F.base_el);
         rs_r = make_rsrc(a.r + F.base_el);
@@ -1131,7 +1165,8 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     // `own`: the row is one of this item's rows (its r / x / u / previous direction are needed, and its edge element)
     auto fetch = [&]() -> Raw {
         if (f_have && f_idx > F.nrows) {
-            f_item += seq.step; f_have = f_item < seq.end;
+            f_item = dq ? seq.begin + seq.step + __builtin_amdgcn_readfirstlane(dq_ticket) * dq_nsub + dq_sub : f_item + seq.step;
+            f_have = f_item < seq.end;
             if (f_have) enter(f_item);
         }
         const bool own = f_have && f_idx >= 0 && f_idx < F.nrows;
@@ -1152,7 +1187,6 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
     };
 
     // ---- compute cursor ----
-    int c_item = f_item;
     bool c_have = f_have;
     ItemAddr C{};
     int c_idx = -1, c_so = 0, c_y = 0;
@@ -1288,7 +1322,7 @@ __global__ __launch_bounds__(kBlock) void k_update_st(const UpdateStArgs<T> a) {
                     p_b = c.p; c = w;
                 }
                 if (c_idx == C.nrows) {
-                    c_item += seq.step; c_have = c_item < seq.end;
+                    c_have = f_have;                          // see k_stencil
                     if (c_have) promote();
                 } else ++c_idx;
             }

@@ -92,6 +92,8 @@ struct mi355cg_ctx {
     mi355cg_params dist_prm{};                    // slab mode: parameters given to mi355cg_dist_begin
     bool dist_active = false, is_slab = false;
     CgState *sA = nullptr, *sB = nullptr, *summary = nullptr;
+    int* qctr = nullptr;                // dynamic item queues: kXcds * kQueueSubs counters of the stencil launches, then as many of the update launches (QueueSpec)
+    int dyn_rows = 0;                   // > 0: the whole-part launches cut their items this short and deal them through the queues
     int* stop_h = nullptr;              // pinned host word: a stop request, sampled by block 0 of every update launch (msg_solver.cpp:82-87)
     int* stop_dev = nullptr;            // the same word as the device addresses it (nullptr while no solve with a stop flag is running)
     HistEntry* hist = nullptr;
@@ -208,7 +210,7 @@ long long add_panel(WorkList& wl, int y0, int y1, int s0, int s1, int ty, int gc
 // becomes further rounds -- which cost nothing since the load pipeline no longer drains between items.  The fp32 kernels
 // (256-column strips) like 64 rows.  The height is then nudged so that the items fill a whole number of rounds: a last
 // round with a few items would run at a fraction of the chip.
-Plan make_plan(const std::vector<Rect>& rects, int max_rows, int fixed_ty = 0) {
+Plan make_plan(const std::vector<Rect>& rects, int max_rows, int fixed_ty = 0, int dyn_rows = 0) {
     Plan pl{};
     const int target_waves = std::max(kWaves, env_int("MI355CG_WAVES", 2048));
     const int max_blocks = std::max(1, env_int("MI355CG_BLOCKS", 512));
@@ -235,7 +237,11 @@ Plan make_plan(const std::vector<Rect>& rects, int max_rows, int fixed_ty = 0) {
         return wl.nitems <= rounds * waves;
     };
     int ty = fixed_ty;
-    if (ty <= 0) {
+    if (ty <= 0 && dyn_rows > 0 && classes) {
+        // dynamic queues: short items, several per wave; no need to fill whole rounds -- whoever is early takes more
+        ty = dyn_rows;
+        pl.wl = build(ty);
+    } else if (ty <= 0) {
         const long long rounds = std::max<long long>(1, (strip_rows + waves * item_rows - 1) / (waves * item_rows));
         ty = (int)std::max<long long>(std::min<long long>(8, item_rows), (strip_rows + rounds * waves - 1) / (rounds * waves));
         for (int tries = 0; tries < 64; ++tries) {
@@ -259,7 +265,16 @@ void build_plans(mi355cg_ctx* c) {
     Rect rr[2];
     const int nr = region_rects(gp, 2, g.y_lo, g.y_hi, c->s_lo, c->s_hi, rr);
     std::vector<Rect> whole(rr, rr + nr);
+    // Static deal (one round of tall items) or run-time item queues (short items, QueueSpec)?  Measured (profiles/r03_tune_notes.md
+    // section 5): the queues lose 1.5 % at N = 4096 (49-row items: the balancing gain and the cost of short items cancel) and win
+    // +1-3 % at N = 8192, +3-5 % at N = 16384, +5-8 % at N = 32768, where the static items are hundreds of rows tall and the launch
+    // tail is whole items.  Default: queues of 16-row items when the static items would be at least 96 rows tall.  MI355CG_DYN_ROWS = 0 | R overrides.
     c->whole = make_plan(whole, kMaxRowsF64);
+    c->dyn_rows = std::max(0, env_int("MI355CG_DYN_ROWS", c->whole.ty >= 96 ? 16 : 0));
+    if (c->dyn_rows > 0) {
+        const Plan dyn = make_plan(whole, kMaxRowsF64, 0, c->dyn_rows);
+        if (dyn.wl.ncls == kXcds && dyn.wl.nitems >= 2 * kWaves * dyn.grid) c->whole = dyn; else c->dyn_rows = 0;      // small launches keep the static deal
+    }
     c->has_gc = false;
     for (auto& r : whole) if (r.gc) c->has_gc = true;
     // split for halo / compute overlap: `edge` = everything that reads ghost data of r (first and last owned row, the
@@ -340,6 +355,7 @@ void launch_iteration_stencil(mi355cg_ctx* c, const IterCfg& cfg, const T* r, T*
     a.s_in = c->sB; a.s_out = c->sA; a.hist = c->hist; a.rp = cfg.rp; a.want_diag = cfg.want_diag;
     a.store_ghosts = c->is_slab ? 1 : 0;
     if (fl) a.fl = *fl;
+    if (VEC == 2 && c->dyn_rows > 0 && w.plan == &c->whole) a.dq = QueueSpec{c->qctr, c->qctr + kXcds * kQueueSubs * kQueuePitch};
     const dim3 grid(w.plan->grid), block(kBlock);
     const bool msg = cfg.rp.rule == MI355CG_RULE_MSG_MAXNORM, gc = c->has_gc, d3 = c->depth == 3;
 #define MI355CG_ST(MSG, D, GC) hipLaunchKernelGGL((k_stencil<T, VEC, true, MSG, D, true, GC>), grid, block, 0, w.stream, a)
@@ -365,6 +381,7 @@ void launch_iteration_update(mi355cg_ctx* c, const IterCfg& cfg, T* x, T* r, T* 
     a.partB = c->partB; a.strideB = c->strideB; a.slotB = w.slot;
     a.s_in = c->sA; a.s_out = c->sB; a.rule = cfg.rp.rule; a.reverse = 1;
     if (fl) a.fl = *fl;
+    if (VEC == 2 && c->dyn_rows > 0 && w.plan == &c->whole) a.dq = QueueSpec{c->qctr + kXcds * kQueueSubs * kQueuePitch, c->qctr};
     a.stop_req = w.slot == 0 ? c->stop_dev : nullptr;   // block 0 samples the pinned stop word once per iteration (of a phase in two launches: the one that runs last and owns slot 0)
     const dim3 grid(w.plan->grid), block(kBlock);
     const bool d3 = c->depth == 3 && !(cfg.x2 && c->cur == 0 && c->xsteps == 8);
@@ -820,6 +837,7 @@ static int create_impl(int n, int m, double a, double b, double c_, double d, in
     }
     hipMemset(c->sA, 0, sizeof(CgState)); hipMemset(c->sB, 0, sizeof(CgState)); hipMemset(c->summary, 0, sizeof(CgState));
     hipMemset(c->hist, 0, sizeof(HistEntry) * kHist);
+    if (hipMalloc((void**)&c->qctr, sizeof(int) * 2 * kXcds * kQueueSubs * kQueuePitch) != hipSuccess || hipMemset(c->qctr, 0, sizeof(int) * 2 * kXcds * kQueueSubs * kQueuePitch) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "queue counter allocation failed"); return cleanup(); }
     if (hipHostMalloc((void**)&c->stop_h, sizeof(int)) != hipSuccess) { rc = fail(MI355CG_ERR_HIP, "stop word allocation failed"); return cleanup(); }
     *c->stop_h = 0;
     // The zero-fills above run on the NULL stream and are asynchronous to the host; the context's own stream is
@@ -932,7 +950,7 @@ void mi355cg_destroy(mi355cg_handle c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->x, c->r, c->p[0], c->p[1], c->p[2], c->p[3], c->p[4], c->p[5], c->p[6], c->p[7], c->ap, c->b, c->u, c->scratch[0], c->scratch[1], c->xf, c->rf,
                    c->pf[0], c->pf[1], c->pf[2], c->pf[3], c->pf[4], c->pf[5], c->pf[6], c->pf[7], c->apf,
-                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist};
+                   c->packed, c->partA, c->partB, c->partR, c->sumsA, c->sumsB, c->sA, c->sB, c->summary, c->hist, c->qctr};
     for (void* p : dev) if (p) hipFree(p);
     if (c->csr_row_map) hipFree(c->csr_row_map);
     if (c->csr_entries) hipFree(c->csr_entries);
@@ -1066,6 +1084,7 @@ int mi355cg_solve(mi355cg_handle c, const mi355cg_params* prm, mi355cg_iter_cb c
     // vectors were allocated and no launch writes anything but zeros there; the other directions of the ring are written
     // (iterations 1 .. M-1) before the folded x update first reads them (iteration M).
     c->cur = 0;
+    if (c->qctr && c->dyn_rows > 0) HIPCK(hipMemsetAsync(c->qctr, 0, sizeof(int) * 2 * kXcds * kQueueSubs * kQueuePitch, c->stream));
     {
         FreshArgs<double> f{};
         f.begin = c->g.own_begin / 2; f.nvec = c->g.own_len / 2;

@@ -982,6 +982,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         // one pass over the owned range (mi355cg_solve does the same); the ghost cells of the first direction are zeroed too:
         // they still hold the neighbours' last direction of the previous solve
         HIPCK(hipMemsetAsync(c->p[0], 0, sizeof(double) * c->storage_len, c->stream));
+        if (c->qctr && c->dyn_rows > 0) HIPCK(hipMemsetAsync(c->qctr, 0, sizeof(int) * 2 * kXcds * kQueueSubs * kQueuePitch, c->stream));
         c->cur = 0;
         {
             FreshArgs<double> f{};

@@ -21,6 +21,9 @@ VARIANTS = [
     {"MI355CG_XSTEPS": "2"},                                # x folded every 2nd iteration instead of every 4th (round 1's scheme)
     {"MI355CG_XCD_CLASSES": "0"},                           # items dealt to all workgroups alike (no per-XCD ranges)
     {"MI355CG_BLOCKS": "100", "MI355CG_ITEM_ROWS": "9"},    # grid not a multiple of 8 XCD classes -> rounded down to 96
+    {"MI355CG_DYN_ROWS": "5"},                              # run-time item queues (experimental): every wave takes its next item from its group's counter
+    {"MI355CG_DYN_ROWS": "3", "MI355CG_BLOCKS": "24"},      # ... with fewer workgroups per XCD class than sub-queues
+    {"MI355CG_DYN_ROWS": "4", "MI355CG_DEPTH": "2"},
 ]
 
 

@@ -22,3 +22,4 @@ def test_no_write_to_the_data_registers_right_after_a_128_bit_buffer_store(tmp_p
     assert text.count("buffer_store_dwordx4") > 50                      # the check looked at the real kernels
     bad = chk.findings(dump)
     assert not bad, "\n".join(f"{k}: {st} -> {wr} after {n} wait state(s)" for k, st, wr, n in bad)
+

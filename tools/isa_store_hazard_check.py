@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def compile_to_asm(out):
     src = os.path.join(ROOT, "iterative_solvers_amd", "csrc")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-w", "--cuda-device-only", "-S",
-                           "-o", out, "mi355cg.hip"], cwd=src)
+                           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-o", out, "mi355cg.hip"], cwd=src)
 
 
 def regs(tok):

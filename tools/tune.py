@@ -21,7 +21,7 @@ ITERS = int(pos[1]) if len(pos) > 1 else 400
 F32 = len(pos) > 2 and pos[2] == "f32"
 U = (N // 2 - 1) * (3 * N // 2 - 1)
 WB = 4 if F32 else 8
-KNOBS = ("MI355CG_XSTEPS", "MI355CG_ITEM_ROWS", "MI355CG_WAVES", "MI355CG_BLOCKS", "MI355CG_DEPTH", "MI355CG_GRAPH", "MI355CG_XCD_CLASSES")
+KNOBS = ("MI355CG_DYN_ROWS", "MI355CG_XSTEPS", "MI355CG_ITEM_ROWS", "MI355CG_WAVES", "MI355CG_BLOCKS", "MI355CG_DEPTH", "MI355CG_GRAPH", "MI355CG_XCD_CLASSES")
 
 
 def measure(cfg):
