@@ -190,11 +190,17 @@ def run_leg_child(spec, args):
     run(args.warmup)
     times = []
     for _ in range(repeats(args, 0.14 * max(1.0, U / nparts / 12.6e6))):
+        # K iterations between barrier + device synchronisation on both sides.  Every rank reads its clock when ITS device is done
+        # and before it enters the closing barrier (a gloo barrier over TCP costs 0.2 - 1 ms, a tenth of a 20-iteration window and
+        # no part of the solve); the job's time is the maximum over the ranks.
         barrier()
         t0 = time.perf_counter()
         res = run(args.steps)
-        barrier()
-        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if not local:
+            dist.barrier()
+        dt = torch.tensor([t1 - t0], dtype=torch.float64)
         if not local:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         times.append(float(dt.item()))
