@@ -980,8 +980,14 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         c->stop_dev = nullptr;
         HIPCK(hipHostGetDevicePointer((void**)&c->stop_dev, t->stop_h, 0));
         // one pass over the owned range (mi355cg_solve does the same); the ghost cells of the first direction are zeroed too:
-        // they still hold the neighbours' last direction of the previous solve
-        HIPCK(hipMemsetAsync(c->p[0], 0, sizeof(double) * c->storage_len, c->stream));
+        // they still hold the neighbours' last direction of the previous solve.  Row slabs: the two ghost rows; 2-D parts: the
+        // whole vector (ghost columns are strided); a part that is the whole grid has no ghost cells.
+        if (c->is_slab && c->has_gc) HIPCK(hipMemsetAsync(c->p[0], 0, sizeof(double) * c->storage_len, c->stream));
+        else if (c->is_slab) {
+            const Geom& g = c->g;
+            for (int y : {g.y_lo - 1, g.y_hi + 1})
+                HIPCK(hipMemsetAsync(c->p[0] + (phys_start(g, y) - g.base0), 0, sizeof(double) * (size_t)(phys_end(g, y) - phys_start(g, y)), c->stream));
+        }
         if (c->qctr && c->dyn_rows > 0) HIPCK(hipMemsetAsync(c->qctr, 0, sizeof(int) * 2 * kXcds * kQueueSubs * kQueuePitch, c->stream));
         c->cur = 0;
         {
