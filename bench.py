@@ -118,7 +118,7 @@ TRANSPORTS = {
     "rccl-inline": ({"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "inline", "MI355CG_TEAM_IPC": "0"},
                     "records: ncclAllGather, halo: one ncclSend/ncclRecv group, both on the compute stream of ONE communicator (order-safe)"),
     "mailbox+push": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "auto"},
-                     "records: stored by the producer launch's last block straight into every rank's IPC-mapped mailbox, polled by the consumer launch; "
+                     "records: a one-workgroup reducer launch beside the producer stores them straight into every OTHER rank's IPC-mapped mailbox; the consumer launch reduces its own partials and polls only for the others; "
                      "halo: pushed into the neighbours' ghost cells by one small launch + a stream-ordered flag (RCCL only bootstraps)"),
     "rccl-stream": ({"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "stream", "MI355CG_TEAM_IPC": "0"},
                     "records: ncclAllGather on the compute stream, halo: ncclSend/ncclRecv on a second stream + second communicator"),

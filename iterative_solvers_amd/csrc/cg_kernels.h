@@ -437,48 +437,68 @@ struct ReduceArgs {
     unsigned stamp; u64 budget;
     RecSpec rs;
 };
+// Small on purpose (a few dozen VGPRs, no LDS staging): it has to become resident beside a producer launch that fills the CUs.
 __global__ __launch_bounds__(kBlock) void k_reduce_ll(const ReduceArgs a) {
-    __shared__ double vals[FB_LL_COUNT * kMaxPartSlots];   // field-major: vals[f * nslots + slot]
     __shared__ double lds[2 * kWaves];
     __shared__ double rec[kRecWords];
     const int nf = a.which == 0 ? FA_COUNT : FB_LL_COUNT, n = a.nslots;
+    const int nsum = a.which == 0 ? kNumSumsA : kNumSumsB, lo_off = a.which == 0 ? FA_LO : FB_LO;
     if (threadIdx.x < kRecWords) rec[threadIdx.x] = 0.0;
-    unsigned* out = reinterpret_cast<unsigned*>(vals);
-    const int nw = n * 2 * nf;
+    // Thread t takes slots t, t + 256, ... in ascending order -- reduce_parts_dd's assignment -- and polls each slot's words itself.
+    dd sum[kNumSumsB] = {dd_zero(), dd_zero(), dd_zero()};
+    double mx[4] = {0.0, 0.0, 0.0, 0.0};                  // update phase: rmax, dmax, emax, stop
     int bad = 0;
     const u64 t0 = wall_clock64();
-    for (int i = threadIdx.x; i < nw && !bad; i += kBlock) {
-        u64 v = ld_sys(a.part + i);
-        unsigned spins = 0;
-        for (;;) {
-            // a stamp is 0x80000000 | (sequence number mod 2^31); 0 = never written.  A NEWER stamp: the launches of a later iteration
-            // have already overwritten the words -- only possible once the solve is over and launches return in their prologue -- so
-            // nobody waits for this record any more.
-            const unsigned st = (unsigned)(v >> 32);
-            const int ahead = (st & 0x80000000u) ? (int)((st - a.stamp) << 1) : -1;
-            if (ahead == 0) break;
-            if (ahead > 0) { bad = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-            v = ld_sys(a.part + i);
-            if ((++spins & 31u) == 0 && wall_clock64() - t0 > a.budget) { bad = 1; break; }
+#pragma unroll 1
+    for (int slot = threadIdx.x; slot < n && !bad; slot += kBlock) {
+        const u64* w = a.part + (long long)slot * (2 * nf);
+        double val[FB_LL_COUNT];
+#pragma unroll
+        for (int f = 0; f < FB_LL_COUNT; ++f) {
+            val[f] = 0.0;
+            if (f < nf && !bad) {
+                unsigned half[2] = {0u, 0u};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u64 v = ld_sys(w + 2 * f + h);
+                    unsigned spins = 0;
+                    for (;;) {
+                        // a stamp is 0x80000000 | (sequence number mod 2^31); 0 = never written.  A NEWER stamp: the launches of a later
+                        // iteration have already overwritten the words -- only possible once the solve is over and launches return in
+                        // their prologue -- so nobody waits for this record any more.
+                        const unsigned st = (unsigned)(v >> 32);
+                        const int ahead = (st & 0x80000000u) ? (int)((st - a.stamp) << 1) : -1;
+                        if (ahead == 0) break;
+                        if (ahead > 0) { bad = 1; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                        v = ld_sys(w + 2 * f + h);
+                        if ((++spins & 31u) == 0 && wall_clock64() - t0 > a.budget) { bad = 1; break; }
+                    }
+                    half[h] = (unsigned)v;
+                }
+                val[f] = __builtin_bit_cast(double, ((u64)half[1] << 32) | half[0]);
+            }
         }
-        const int slot = i / (2 * nf), w = i - slot * (2 * nf);
-        out[2 * ((w >> 1) * n + slot) + (w & 1)] = (unsigned)v;
+#pragma unroll
+        for (int f = 0; f < kNumSumsB; ++f) if (f < nsum) sum[f] = dd_add(sum[f], dd{val[f], val[f + lo_off]});
+        if (a.which == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mx[k] = fmax(mx[k], val[FB_RMAX + k]);       // FB_RMAX, FB_DMAX, FB_EMAX, FB_STOP are consecutive
+        }
     }
     if (__syncthreads_or(bad)) return;            // superseded, or timed out: then the consumers miss the record too and end the solve
-    const int nsum = a.which == 0 ? kNumSumsA : kNumSumsB, lo_off = a.which == 0 ? FA_LO : FB_LO;
-    for (int f = 0; f < nsum; ++f) {
-        const dd t = reduce_parts_dd(vals + f * n, vals + (f + lo_off) * n, n, 1, lds);
+#pragma unroll
+    for (int f = 0; f < kNumSumsB; ++f) if (f < nsum) {
+        const dd t = block_reduce_dd(sum[f], lds);
         if (threadIdx.x == 0) { rec[f] = t.hi; rec[f + lo_off] = t.lo; }
     }
     if (a.which == 1) {
-        for (int k = 0; k < 3; ++k) {
-            const double t = reduce_parts<true>(vals + (FB_RMAX + k) * n, n, 1, lds);
-            if (threadIdx.x == 0) rec[FB_RMAX + k] = t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double t = block_reduce<true>(mx[k], lds);
+            // k = 3: the stop request as the update launch itself sampled it (the launch's own part acts on the same sample through its state)
+            if (threadIdx.x == 0) rec[k < 3 ? FB_RMAX + k : kRecStopWord] = t;
         }
-        // the stop request as the update launch itself sampled it (the launch's own part acts on the same sample through its state)
-        const double t = reduce_parts<true>(vals + FB_STOP * n, n, 1, lds);
-        if (threadIdx.x == 0) rec[kRecStopWord] = t;
     }
     __syncthreads();
     publish_record(rec, a.rs);
