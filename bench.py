@@ -132,18 +132,19 @@ def plan_legs(args):
     N = args.gpus
     base = {"scaling": args.scaling, "decomp": args.decomp, "grid": args.n, "driver": "ranks"}
     legs = [dict(base, name="rccl-inline", transport="rccl-inline", headline=True),
-            dict(base, name="mailbox+push", transport="mailbox+push", headline=True)]
-    if args.legs == "all":
-        legs.append(dict(base, name="rccl-stream", transport="rccl-stream", headline=False))
-        if not (args.scaling == "strong" and args.n == 32768):
-            legs.append(dict(base, name="config5-strong-32768", transport="mailbox+push", headline=False, scaling="strong", grid=32768, decomp="rows", verify=0))
-        if N == 4 and not (args.decomp == "2d" and args.scaling == "strong" and args.n == 16384):
-            legs.append(dict(base, name="config4-2x2-16384", transport="mailbox+push", headline=False, scaling="strong", grid=16384, decomp="2d"))
-        if N > 1:          # last: in the torchrun form only rank 0's coordinator runs it, while the others are already done
-            legs.append(dict(base, name="local-one-process", transport="local", headline=False, driver="local"))
-    elif args.legs != "default":
+            dict(base, name="mailbox+push", transport="mailbox+push", headline=True),
+            dict(base, name="rccl-stream", transport="rccl-stream", headline=False)]
+    if not (args.scaling == "strong" and args.n == 32768):
+        legs.append(dict(base, name="config5-strong-32768", transport="mailbox+push", headline=False, scaling="strong", grid=32768, decomp="rows", verify=0))
+    if N == 4 and not (args.decomp == "2d" and args.scaling == "strong" and args.n == 16384):
+        legs.append(dict(base, name="config4-2x2-16384", transport="mailbox+push", headline=False, scaling="strong", grid=16384, decomp="2d"))
+    if N > 1:          # last: in the torchrun form only rank 0's coordinator runs it, while the others are already done
+        legs.append(dict(base, name="local-one-process", transport="local", headline=False, driver="local"))
+    if args.legs == "default":
+        legs = legs[:2]
+    elif args.legs != "all":
         want = args.legs.split(",")
-        legs = [l for l in legs if l["name"] in want] + [dict(base, name=w, transport=w, headline=True) for w in want if w in TRANSPORTS and w not in ("rccl-inline", "mailbox+push")]
+        legs = [l for l in legs if l["name"] in want] + [dict(base, name=w, transport=w, headline=True) for w in want if w in TRANSPORTS and w not in [l["name"] for l in legs]]
     return legs
 
 
@@ -159,7 +160,11 @@ def run_leg_child(spec, args):
     world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
     local = spec["driver"] == "local"
     nparts = args.gpus if local else world
-    torch.cuda.set_device(local_rank)
+    # Rehearsal on a one-GPU box (MI355CG_BENCH_ONE_GPU=1 + MI355CG_RCCL_LIB = the tests' nccl stand-in, because RCCL refuses two
+    # ranks on one device): every rank uses device 0; everything else -- coordinators, legs, clocks, cross-check -- is the real thing.
+    dev = 0 if os.environ.get("MI355CG_BENCH_ONE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev)
+    open(f"{args.child_out}.r{rank}.ready", "w").close()             # imports done: the leg's clock starts when every rank is here
     if not local:
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))       # control plane only: the id, barriers, max over ranks
     rule = _capi.RULE_REL_2NORM if args.rule == "rel2" else _capi.RULE_MSG_MAXNORM
@@ -172,7 +177,7 @@ def run_leg_child(spec, args):
     if local:
         team = D.Team.local(n, nparts, decomp, devices=list(range(min(ndev, nparts))))
     else:
-        team = D.Team.rccl(n, decomp, device=local_rank)
+        team = D.Team.rccl(n, decomp, device=dev)
     desc = team.describe()
     if not local and desc["rccl_nranks"] != args.gpus:
         raise RuntimeError(f"RCCL reports {desc['rccl_nranks']} ranks, --gpus asked for {args.gpus}")
@@ -221,7 +226,7 @@ def run_leg_child(spec, args):
         rv = run(nverify)
         torch.cuda.synchronize()
         if rank == 0:
-            one = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=local_rank)
+            one = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, device=dev)
             p = isa.default_params(rule)
             p.max_iterations, p.fixed_iterations, p.use_true_solution, p.callback_every, p.sync_every = nverify, 1, 0, 0, 500
             r1 = one._handle.solve(p)
@@ -270,7 +275,8 @@ def child_main(args):
 def leg_command(args, spec, out_path):
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--grid", str(args.n), "--rule", args.rule, "--verify", str(args.verify), "--verify-max-unknowns", str(args.verify_max_unknowns),
-           "--repeats", str(args.repeats), "--child-leg", json.dumps(spec), "--child-out", out_path]
+           "--repeats", str(args.repeats), "--leg-timeout", str(args.leg_timeout), "--import-allowance", str(args.import_allowance),
+           "--child-leg", json.dumps(spec), "--child-out", out_path]
     return cmd
 
 
@@ -289,8 +295,49 @@ def leg_env(base_env, spec, rank, world, local_rank, port):
     return env
 
 
+class _Terminated(Exception):
+    pass
+
+
+def _write_json(path, obj):
+    tmp = f"{path}.tmp{os.getpid()}"
+    with open(tmp, "w") as f:
+        json.dump(obj, f)
+    os.replace(tmp, path)                                          # readers see the whole file or none of it
+
+
+def _read_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def meeting_dir(launched, world, now):
+    """Where the coordinators of one invocation meet.  Without a launcher there is one coordinator and the directory is its own.
+    Under torchrun every worker is the coordinator of ONE rank; all of them run on this node (--nnodes=1), so they agree on a
+    directory named after what the launcher gave all of them alike, and rank 0's coordinator (the lead) opens the session there.
+    A session file left by an earlier invocation with the same port is told by its age."""
+    if not launched:
+        return tempfile.mkdtemp(prefix="mi355cg_bench_")
+    d = os.path.join(tempfile.gettempdir(), "mi355cg_bench_%s_%s_w%d" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "0"), world))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
 def coordinate(args):
-    """Start the rank processes of every leg, watch them, collect rank 0's record.  Touches no GPU (imports no torch)."""
+    """Start the rank processes of every leg, watch them, collect rank 0's record.  Touches no GPU (imports no torch).
+
+    Time: the driver kills a bench run after 600 s, and a killed run leaves no line.  So everything here ends by `--budget` seconds
+    (420) after the start, whatever the legs do: a leg gets `--leg-timeout` seconds from the moment all its ranks have finished
+    importing (the first import of torch on a fresh box can take two minutes), never more than what is left of the budget; a leg is
+    not started with less than 45 s left.  SIGTERM ends the current leg and still prints the line.
+
+    Under torchrun the coordinators act in step through files in a directory they share (same node): the lead says for every leg
+    whether it is run and until when, every coordinator says when its rank is ready or has failed, the lead says when the leg is
+    over -- so no coordinator waits for ranks another one never started, or keeps a rank alive that the lead has given up on."""
+    t_start = time.time()
     launched = int(os.environ.get("WORLD_SIZE", "1")) > 1          # torchrun (the driver's N > 1 form): this process is ONE rank's coordinator
     world = args.gpus
     if launched and int(os.environ["WORLD_SIZE"]) != args.gpus:
@@ -301,67 +348,144 @@ def coordinate(args):
     base_port = int(os.environ.get("MASTER_PORT", "29531")) + 101   # the launcher's own store keeps MASTER_PORT
     legs = plan_legs(args)
     results, notes = {}, []
-    t_start = time.time()
-    tmpdir = tempfile.mkdtemp(prefix="mi355cg_bench_")
-    for li, spec in enumerate(legs):
-        if time.time() - t_start > args.budget and results:
-            notes.append(f"leg {spec['name']} not started: {args.budget:.0f} s budget used up")
-            continue
-        local = spec["driver"] == "local"
-        if local and not lead:
-            continue
-        out_path = os.path.join(tmpdir, f"leg{li}")
-        ranks = [0] if local else my_ranks
-        procs = []
-        for r in ranks:
-            env = leg_env(os.environ, spec, 0 if local else r, 1 if local else world, local_of.get(r, 0), base_port + li)
-            log = open(os.path.join(tmpdir, f"leg{li}.r{r}.log"), "w")
-            procs.append((r, subprocess.Popen(leg_command(args, spec, out_path), env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True), log))
-        deadline = time.time() + args.leg_timeout
-        alive = list(procs)
-        failed = False
-        while alive and time.time() < deadline:
-            alive = [p for p in alive if p[1].poll() is None]
-            if any(p[1].returncode not in (None, 0) for p in procs):
-                failed = True
-                deadline = min(deadline, time.time() + 20.0)             # a rank died: the others are waiting for it in vain
-            time.sleep(0.05)
-        stalled = bool(alive)
-        for r, p, log in alive:                                           # exactly the process groups started above
+    t_end = t_start + args.budget
+    meet = meeting_dir(launched, world, t_start)
+    session = os.path.join(meet, "session")
+    if lead:
+        for f in os.listdir(meet):                                  # whatever an earlier invocation left here
             try:
-                os.killpg(p.pid, signal.SIGKILL)
-            except ProcessLookupError:
+                os.unlink(os.path.join(meet, f))
+            except OSError:
                 pass
+        _write_json(session, {"t_start": t_start, "pid": os.getpid()})
+    else:
+        while time.time() < min(t_end, t_start + 90.0):
+            got = _read_json(session)
+            if got and abs(got["t_start"] - t_start) < 60.0:
+                t_end = got["t_start"] + args.budget                # one clock for all: the lead's
+                break
+            time.sleep(0.05)
+        else:
+            return None                                             # no lead (it failed before it got here): nothing to take part in
+
+    def on_term(signum, frame):
+        raise _Terminated()
+    import threading
+    hook = lead and threading.current_thread() is threading.main_thread()
+    old_term = signal.signal(signal.SIGTERM, on_term) if hook else None
+
+    def kill(procs):
+        for r, p, log in procs:                                     # exactly the process groups started here
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
         for r, p, log in procs:
             try:
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 pass
-            log.close()
-        rec = None
-        for r in ranks:
-            f = f"{out_path}.r{r}"
-            if os.path.exists(f):
-                with open(f) as fh:
-                    got = json.load(fh)
-                if r == 0 or "error" in got:
+            if not log.closed:
+                log.close()
+
+    procs = []
+    try:
+        for li, spec in enumerate(legs):
+            local = spec["driver"] == "local"
+            if local and not lead:
+                continue
+            tag = os.path.join(meet, f"leg{li}")
+            # ---- go or skip: the lead's call, the same for every coordinator
+            if lead:
+                left = t_end - time.time()
+                go = left >= min(45.0, args.leg_timeout) or not results
+                if not go:
+                    notes.append(f"leg {spec['name']} not started: {left:.0f} s left of the {args.budget:.0f} s budget")
+                _write_json(tag + ".go", {"go": go})
+            else:
+                got = None
+                while got is None and time.time() < t_end:
+                    got = _read_json(tag + ".go")
+                    if got is None:
+                        time.sleep(0.02)
+                go = bool(got and got["go"])
+                if got is None:
+                    return None
+            if not go:
+                continue
+            ranks = [0] if local else my_ranks
+            need = [0] if local else list(range(world))
+            out_path = tag
+            procs = []
+            for r in ranks:
+                env = leg_env(os.environ, spec, 0 if local else r, 1 if local else world, local_of.get(r, 0), base_port + li)
+                log = open(f"{tag}.r{r}.log", "w")
+                procs.append((r, subprocess.Popen(leg_command(args, spec, out_path), env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True), log))
+            # ---- watch: until all of this coordinator's ranks are gone, the deadline passes, or the lead declares the leg over
+            deadline = min(t_end, time.time() + args.import_allowance + args.leg_timeout)
+            armed = failed = False
+            over = None
+            while time.time() < deadline:
+                alive = [p for p in procs if p[1].poll() is None]
+                for r, p, log in procs:
+                    if p.returncode not in (None, 0) and not os.path.exists(f"{tag}.fail.r{r}"):
+                        _write_json(f"{tag}.fail.r{r}", {"rc": p.returncode})
+                if not alive:
+                    break
+                if not failed and any(os.path.exists(f"{tag}.fail.r{r}") for r in need):
+                    failed = True
+                    deadline = min(deadline, time.time() + 15.0)     # a rank died: the others are waiting for it in vain
+                if not armed:
+                    if lead and all(os.path.exists(f"{out_path}.r{r}.ready") for r in need):
+                        _write_json(tag + ".armed", {"deadline": min(t_end, time.time() + args.leg_timeout)})
+                    got = _read_json(tag + ".armed")
+                    if got:
+                        armed = True
+                        deadline = min(deadline, got["deadline"]) if failed else got["deadline"]
+                if not lead and over is None and os.path.exists(tag + ".over"):
+                    over = time.time()
+                    deadline = min(deadline, over + 10.0)             # the lead is done with this leg: a rank still running is stuck
+                time.sleep(0.05)
+            stalled = any(p[1].poll() is None for p in procs)
+            kill(procs)
+            if lead:
+                _write_json(tag + ".over", {"stalled": stalled})
+            rec = None
+            for r in need:
+                got = _read_json(f"{out_path}.r{r}")
+                if got is not None and (r == 0 or "error" in got):
                     rec = got if rec is None or "error" in got else rec
-        if lead:
-            if rec is None:
-                tail = ""
-                try:
-                    with open(os.path.join(tmpdir, f"leg{li}.r0.log")) as fh:
-                        tail = fh.read()[-400:]
-                except OSError:
-                    pass
-                rec = {"leg": spec["name"], "error": ("stalled: killed after %.0f s" % args.leg_timeout) if stalled and not failed else f"no record (rank exit codes {[p[1].returncode for p in procs]}): {tail}"}
-            elif stalled and "error" not in rec:
-                rec["note"] = "some ranks had to be killed after the record was written"
-            rec["what"] = TRANSPORTS.get(spec["transport"], (None, "one process drives all parts (LOCAL transport: peer access, one host thread per device)"))[1]
-            rec["headline_candidate"] = bool(spec["headline"])
-            results[spec["name"]] = rec
+            if lead:
+                if rec is None:
+                    tail = ""
+                    try:
+                        with open(f"{tag}.r0.log") as fh:
+                            tail = fh.read()[-400:]
+                    except OSError:
+                        pass
+                    why = "the imports" if not armed else "%.0f s" % args.leg_timeout
+                    rec = {"leg": spec["name"], "error": (f"stalled: killed after {why} ({time.time() - t_start:.0f} s into the run)") if stalled and not failed
+                           else f"no record (rank exit codes {[p[1].returncode for p in procs]}): {tail}"}
+                elif stalled and "error" not in rec:
+                    rec["note"] = "some ranks had to be killed after the record was written"
+                rec["what"] = TRANSPORTS.get(spec["transport"], (None, "one process drives all parts (LOCAL transport: peer access, one host thread per device)"))[1]
+                rec["headline_candidate"] = bool(spec["headline"])
+                results[spec["name"]] = rec
+            procs = []
+    except _Terminated:
+        kill(procs)
+        for lj in range(len(legs)):                                  # the other coordinators: this leg is over, no later one is run
+            for suffix, obj in ((".over", {"stalled": True}), (".go", {"go": False})):
+                if not os.path.exists(os.path.join(meet, f"leg{lj}{suffix}")):
+                    _write_json(os.path.join(meet, f"leg{lj}{suffix}"), obj)
+        notes.append(f"SIGTERM {time.time() - t_start:.0f} s into the run: the legs not listed were not run")
+    finally:
+        if hook:
+            signal.signal(signal.SIGTERM, old_term)
     if not lead:
         return None
+    coordinate.elapsed_s = round(time.time() - t_start, 1)
     return legs, results, notes
 
 
@@ -399,6 +523,7 @@ def compose(args, legs, results, notes):
     else:
         out["error"] = "no leg of the requested configuration produced a record"
     out["legs"] = results
+    out["coordinator"] = {"seconds": getattr(coordinate, "elapsed_s", None), "budget_s": args.budget, "leg_timeout_s": args.leg_timeout, "import_allowance_s": args.import_allowance}
     if notes:
         out["notes"] = notes
     return out
@@ -516,15 +641,16 @@ def main():
     ap.add_argument("--verify", type=int, default=30, help="N > 1: iterations of the untimed cross-check against one GPU (0 = skip)")
     ap.add_argument("--verify-max-unknowns", type=float, default=2.6e8, help="skip that cross-check above this size (host set-up time)")
     ap.add_argument("--legs", default="all", help="N > 1: all | default (the two headline transports only) | comma-separated leg names")
-    ap.add_argument("--leg-timeout", type=float, default=240.0, help="seconds after which the processes of one leg are killed")
-    ap.add_argument("--budget", type=float, default=900.0, help="seconds after which no further leg is started")
+    ap.add_argument("--leg-timeout", type=float, default=110.0, help="seconds a leg gets once all its ranks have finished importing; then its processes are killed")
+    ap.add_argument("--import-allowance", type=float, default=150.0, help="seconds the ranks of a leg may take to start up (first import of torch on a fresh box)")
+    ap.add_argument("--budget", type=float, default=420.0, help="seconds after which the coordinator has ended every leg and prints (the driver kills a run after 600 s)")
     ap.add_argument("--child-leg", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--child-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.child_leg:                                            # a rank process of one leg
         import threading
-        wd = threading.Timer(args.leg_timeout + 30.0, lambda: os._exit(3))     # last resort: never outlive the coordinator's patience
+        wd = threading.Timer(args.import_allowance + args.leg_timeout + 30.0, lambda: os._exit(3))     # last resort: never outlive the coordinator's patience
         wd.daemon = True
         wd.start()
         child_main(args)

@@ -16,7 +16,7 @@ import bench  # noqa: E402
 
 def _args(**kw):
     a = types.SimpleNamespace(gpus=8, steps=20, warmup=5, n=4096, rule="rel2", dtype="f64", scaling="weak", decomp="rows", cpu_iters=0,
-                              no_roofline_pass=False, repeats=0, verify=30, verify_max_unknowns=2.6e8, legs="all", leg_timeout=20.0, budget=900.0,
+                              no_roofline_pass=False, repeats=0, verify=30, verify_max_unknowns=2.6e8, legs="all", leg_timeout=20.0, import_allowance=20.0, budget=420.0,
                               child_leg=None, child_out=None)
     for k, v in kw.items():
         setattr(a, k, v)
@@ -64,6 +64,10 @@ STUB = r"""
 import json, os, sys, time
 spec = json.loads(sys.argv[sys.argv.index("--child-leg") + 1]); out = sys.argv[sys.argv.index("--child-out") + 1]
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if os.environ.get("STUB_NEVER_READY") == "1":
+    time.sleep(600)
+open(out + ".r%d.ready" % rank, "w").close()
+time.sleep(float(os.environ.get("STUB_WORK_S", "0")))
 if spec["name"] == "rccl-stream":
     time.sleep(600)                                    # a collective that never completes
 if spec["name"] == "config5-strong-32768" and rank == world - 1:
@@ -114,16 +118,79 @@ def test_an_unverified_leg_is_not_the_headline(stub, monkeypatch):
     assert out["legs"]["mailbox+push"]["verify_against_one_gpu"]["ok"] is False
 
 
-def test_coordinator_as_a_launcher_worker_starts_only_its_own_rank(stub, monkeypatch, tmp_path):
-    args = _args(gpus=2, legs="default", leg_timeout=5.0)
-    monkeypatch.setenv("WORLD_SIZE", "2")
-    monkeypatch.setenv("RANK", "1")
-    monkeypatch.setenv("LOCAL_RANK", "1")
-    assert bench.coordinate(args) is None                                # not the lead: prints nothing
+DRIVER = r"""
+import json, sys, types
+sys.path.insert(0, sys.argv[1])
+import bench
+stub, kw = sys.argv[2], json.loads(sys.argv[3])
+real = bench.leg_command
+bench.leg_command = lambda args, spec, out: [sys.executable, stub] + real(args, spec, out)[2:]
+args = types.SimpleNamespace(**kw)
+got = bench.coordinate(args)
+if got is not None:
+    print(json.dumps(bench.compose(args, *got)), flush=True)
+"""
+
+
+def _launch_workers(tmp_path, stub, world, port, extra_env=None, **kw):
+    """What torchrun does: `world` workers, each with its RANK -- every one of them a coordinator."""
+    import subprocess
+    drv = tmp_path / "driver.py"
+    drv.write_text(DRIVER)
+    a = vars(_args(gpus=world, **kw))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(drv), ROOT, str(stub), json.dumps(a)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    return procs
+
+
+def _collect(procs, timeout=120):
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    assert [p.returncode for p in procs] == [0] * len(procs), [o[1][-600:] for o in outs]
+    assert all(o[0] == "" for o in outs[1:])                             # only rank 0's coordinator prints
+    return json.loads(outs[0][0])
+
+
+def test_coordinators_under_a_launcher_act_in_step(stub, tmp_path):
+    import time
+    t0 = time.time()
+    out = _collect(_launch_workers(tmp_path, stub, 3, 29700, legs="all", leg_timeout=4.0, import_allowance=5.0))
+    legs = out["legs"]
+    assert legs["rccl-inline"]["n_gpus"] == 3 and legs["rccl-inline"]["transport"]["records"] == "rccl" and out["rccl_nranks"] == 3
+    assert "stalled" in legs["rccl-stream"]["error"]                     # every coordinator gave the leg up at the lead's deadline ...
+    assert "boom" in legs["config5-strong-32768"]["error"]               # ... rank 2's failure reached the lead through the meeting directory ...
+    assert legs["local-one-process"]["n_gpus"] == 1 and out["value"] == 56000.0      # ... and the later legs ran
+    assert time.time() - t0 < 60.0                                       # the failed leg was not waited out: 15 s, not import allowance + limit per coordinator
+
+
+def test_a_world_size_that_disagrees_with_gpus_is_refused(stub, monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "4")
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")
-    legs, results, notes = bench.coordinate(args)
-    assert results["rccl-inline"]["n_gpus"] == 2 and results["rccl-inline"]["transport"]["records"] == "rccl"
-    monkeypatch.setenv("WORLD_SIZE", "4")
     with pytest.raises(SystemExit):
-        bench.coordinate(args)                                           # the launcher's world and --gpus disagree
+        bench.coordinate(_args(gpus=2, legs="default", leg_timeout=5.0))
+
+
+def test_the_budget_ends_the_run_whatever_the_legs_do(stub, tmp_path):
+    import time
+    t0 = time.time()
+    # every leg takes 6 s; 16 s of budget: two legs fit, the third would have < min(45, limit) s left and is not started
+    out = _collect(_launch_workers(tmp_path, stub, 2, 29800, extra_env={"STUB_WORK_S": "6"}, legs="rccl-inline,mailbox+push,mailbox+rccl-halo", leg_timeout=8.0, import_allowance=5.0, budget=16.0))
+    assert time.time() - t0 < 16.0 + 8.0
+    assert set(out["legs"]) == {"rccl-inline", "mailbox+push"} and out["value"] == 56000.0
+    assert any("mailbox+rccl-halo not started" in n for n in out["notes"])
+    # a leg whose ranks never finish importing is cut at what is left of the budget, and the line is still printed
+    t0 = time.time()
+    out = _collect(_launch_workers(tmp_path, stub, 2, 29810, extra_env={"STUB_NEVER_READY": "1"}, legs="default", leg_timeout=50.0, import_allowance=50.0, budget=6.0))
+    assert time.time() - t0 < 6.0 + 8.0 and out["value"] is None and "imports" in out["legs"]["rccl-inline"]["error"] and "mailbox+push" not in out["legs"]
+
+
+def test_sigterm_still_prints_the_line(stub, tmp_path):
+    import signal
+    import time
+    procs = _launch_workers(tmp_path, stub, 2, 29820, extra_env={"STUB_WORK_S": "4"}, legs="default", leg_timeout=30.0, import_allowance=30.0)
+    time.sleep(6.5)                                                      # leg 1 is done, leg 2 is under way
+    procs[0].send_signal(signal.SIGTERM)
+    out = _collect(procs, timeout=90)
+    assert out["value"] == 50000.0 and out["headline_leg"] == "rccl-inline" and any("SIGTERM" in n for n in out["notes"])

@@ -167,6 +167,48 @@ def test_bench_legs_without_a_launcher():
     _check_bench_legs(_bench_line(cmd, env))
 
 
+def _rehearsal_env():
+    from tests import nccl_shim
+    env = dict(os.environ, MI355CG_BENCH_ONE_GPU="1", MI355CG_RCCL_LIB=nccl_shim.build())
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_rehearsal_three_ranks_under_torchrun():
+    """`torchrun --nproc-per-node 3 bench.py --gpus 3` -- the driver's form -- with all three ranks on this box's one GPU
+    (RCCL refuses that, so the ranks talk through tests/nccl_shim): three coordinators in step, fresh rank processes per leg,
+    IPC mailboxes and pushed halos between them, every leg cross-checked against one context."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29881",
+           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "40", "--warmup", "5", "--grid", "768", "--repeats", "3",
+           "--legs", "rccl-inline,mailbox+push,rccl-stream,local-one-process"]
+    j = _bench_line(cmd, _rehearsal_env())
+    assert j["n_gpus"] == 3 and j["rccl_nranks"] == 3 and j["value"] > 0 and "notes" not in j
+    assert set(j["legs"]) == {"rccl-inline", "mailbox+push", "rccl-stream", "local-one-process"}
+    for name, leg in j["legs"].items():
+        assert "error" not in leg, leg
+        assert leg["verify_against_one_gpu"]["ok"] is True and leg["verify_against_one_gpu"]["bit_identical"] is True
+        assert leg["n"] == 1330 and leg["n_gpus"] == 3 and len(leg["decomposition"]["parts"]) == 3
+    push = j["legs"]["mailbox+push"]["transport"]
+    assert (push["records"], push["halo"], push["ipc"], push["shared_device"], push["rccl_nranks"]) == ("mailbox", "push", 1, 1, 3)
+    assert j["legs"]["local-one-process"]["processes"] == 1 and j["coordinator"]["seconds"] < 200
+
+
+def test_bench_rehearsal_config4_shape_without_a_launcher():
+    """`python bench.py --gpus 4 --scaling strong --decomp 2d`: BASELINE config 4's 2 x 2 cut (here of N = 2048), four rank
+    processes started by the one coordinator."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "40", "--warmup", "5", "--grid", "2048", "--scaling", "strong", "--decomp", "2d",
+           "--repeats", "3", "--legs", "default"]
+    j = _bench_line(cmd, _rehearsal_env())
+    assert j["n_gpus"] == 4 and j["rccl_nranks"] == 4 and j["scaling"] == "strong" and j["value"] == j["global_iters_per_sec"]
+    for name in ("rccl-inline", "mailbox+push"):
+        leg = j["legs"][name]
+        assert "error" not in leg, leg
+        assert leg["n"] == 2048 and leg["decomposition"]["kind"] == "2d" and leg["verify_against_one_gpu"]["bit_identical"] is True
+    parts = j["legs"]["mailbox+push"]["decomposition"]["parts"]
+    assert len(parts) == 4 and sum(1 for p in parts if p[2] > 0) == 2   # two columns of parts: ghost COLUMNS cross ranks too
+
+
 def test_slab_handles_refuse_the_whole_grid_entry_points():
     """apply / solve / true-residual on one slab would silently ignore the neighbours' rows: they must fail loudly."""
     import ctypes as C
