@@ -252,6 +252,10 @@ int  mi355cg_team_checksum(mi355cg_team t, int which, double *out2);
 /* which: 2 right-hand side, 3 exact solution: every local part takes its entries of the caller's GLOBAL packed vector -- the b of
  * Solver(a, b, ...) (solver/solver.hpp:33-39) and the true_solution of MSGSolver::solve (msg_solver.cpp:64-72) may be anything.   */
 int  mi355cg_team_set_vector(mi355cg_team t, int which, const double *global_packed);
+/* MI355CG_F32_MIXED: the team's solves become mi355cg_create(..., MI355CG_F32_MIXED)'s algorithm -- fp64 iterative refinement around
+ * an fp32 inner CG (REL_2NORM only) -- across the parts: BASELINE config 3 on more than one GPU.  Row slabs only (the fp32 kernels
+ * march 256-column strips).  Collective.  No reference twin: the reference is fp64 only.                                          */
+int  mi355cg_team_set_dtype(mi355cg_team t, int dtype);
 int  mi355cg_team_setup_on_device(mi355cg_team t);                     /* mi355cg_setup_on_device for every local part */
 int  mi355cg_team_set_profiling(mi355cg_team t, int enable);
 int  mi355cg_team_phase_times(mi355cg_team t, double *kernel_ms, double *comm_ms, double *wall_ms);   /* per iteration */

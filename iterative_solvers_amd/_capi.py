@@ -28,6 +28,7 @@ EXPORTS = [
     "mi355cg_team_create_local", "mi355cg_team_unique_id", "mi355cg_team_create_rccl", "mi355cg_team_destroy",
     "mi355cg_team_solve", "mi355cg_team_info", "mi355cg_team_part", "mi355cg_team_get_vector", "mi355cg_team_set_vector", "mi355cg_team_checksum",
     "mi355cg_team_set_profiling", "mi355cg_team_phase_times", "mi355cg_team_describe", "mi355cg_setup_on_device", "mi355cg_team_setup_on_device", "mi355cg_debug_plan",
+    "mi355cg_team_set_dtype",
 ]
 DECOMP_ROWS, DECOMP_2D = 0, 1
 
@@ -151,6 +152,7 @@ def load():
     L.mi355cg_debug_plan.argtypes = [C.c_int] * 5 + [IP, IP, IP, IP, IP]
     L.mi355cg_setup_on_device.argtypes = [H]
     L.mi355cg_team_setup_on_device.argtypes = [H]
+    L.mi355cg_team_set_dtype.argtypes = [H, C.c_int]
     L.mi355cg_team_set_profiling.argtypes = [H, C.c_int]
     L.mi355cg_team_phase_times.argtypes = [H, DBP, DBP, DBP]
     L.mi355cg_team_describe.argtypes = [H, C.c_char_p, C.c_int]

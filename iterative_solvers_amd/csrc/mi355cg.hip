@@ -74,7 +74,7 @@ struct mi355cg_ctx {
     long long pk_begin = 0, pk_len = 0; // owned cells in the part's packed order (pk_begin: global packed index of the first; row slabs are contiguous)
     PackGeom pg{};
     Plan whole, interior, edge;         // whole part; rows / strips that need no ghost data; the rest (first + last row, edge strips)
-    Plan whole32;                       // fp32 kernels (VEC = 4, 256-column strips), single GPU only
+    Plan whole32;                       // fp32 kernels (VEC = 4, 256-column strips): the whole grid, or a row slab of full width
     int depth = 2;                      // raw rows in flight per wave (env MI355CG_DEPTH: 2 or 3)
     bool has_gc = false;                // 2-D part with a neighbour in x: the stencil launches keep the ghost columns of the direction
     int nB_own = 0;                     // partB slots written by the last update-phase launch(es) of this context
@@ -304,7 +304,8 @@ void build_plans(mi355cg_ctx* c) {
     }
     c->edge.grid = std::max(1, std::min(std::max(1, env_int("MI355CG_BLOCKS", 512)), (c->edge.wl.nitems + kWaves - 1) / kWaves));
     if (c->edge.wl.nitems == 0) c->edge.grid = 0;
-    if (c->dtype == MI355CG_F32_MIXED) {                  // the fp32 kernels use 256-column strips (float4 per lane) on the same pitches
+    // the fp32 kernels use 256-column strips (float4 per lane) on the same pitches; a 2-D part is cut on 128 columns and has none
+    if (c->dtype == MI355CG_F32_MIXED || (c->s_lo == 0 && c->s_hi == strips_total(gp, 2))) {
         Rect r4[2];
         const int n4 = region_rects(gp, 4, g.y_lo, g.y_hi, 0, strips_total(gp, 4), r4);
         c->whole32 = make_plan(std::vector<Rect>(r4, r4 + n4), kMaxRowsF32);
@@ -487,6 +488,22 @@ int ensure_host_copies(mi355cg_ctx* c) {        // device-generated problem data
     if (!c->host_u_valid) { c->u_h.resize(c->pk_len); if (int rc = download_packed<double>(c, c->u, c->u_h.data())) return rc; c->host_u_valid = true; }
     return MI355CG_OK;
 }
+// The fp32 vectors of a team's part (mi355cg_team_set_dtype): correction, direction ring and A p.  The fp32 residual is not among
+// them: a part keeps it in the memory of its fp64 residual vector (what the neighbours' halo messages are addressed to).
+int ensure_f32_vectors(mi355cg_ctx* c) {
+    if (c->xsteps > 4) return fail(MI355CG_ERR_INVALID, "MI355CG_XSTEPS=8 is fp64 only");
+    if (c->whole32.wl.nitems == 0) return fail(MI355CG_ERR_INVALID, "the fp32 kernels march 256-column strips: a part of a 2-D decomposition (cut on 128 columns) cannot run them; use row slabs");
+    if (c->g.own_begin % 4 != 0 || c->g.own_len % 4 != 0) return fail(MI355CG_ERR_STATE, "a part's owned range is not a whole number of float4");
+    float** fv[] = {&c->xf, &c->apf, &c->pf[0], &c->pf[1], &c->pf[2], &c->pf[3]};
+    for (int k = 0; k < 2 + c->xsteps; ++k) {
+        if (*fv[k]) continue;
+        if (hipMalloc((void**)fv[k], sizeof(float) * c->storage_len) != hipSuccess || hipMemset(*fv[k], 0, sizeof(float) * c->storage_len) != hipSuccess)
+            return fail(MI355CG_ERR_HIP, "fp32 vector allocation failed");
+    }
+    HIPCK(hipDeviceSynchronize());
+    return MI355CG_OK;
+}
+
 int ensure_u_on_device(mi355cg_ctx* c) {
     if (c->have_u_dev) return MI355CG_OK;
     if (!c->host_u_valid) return fail(MI355CG_ERR_STATE, "no exact solution on host or device");

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_cols(const ColArgs a) {
 // PUSH halo: this part's boundary rows straight into the neighbours' ghost rows and its packed columns into their receive
 // buffers (their memory: a peer GPU's over xGMI, mapped through IPC when the neighbour is another process).
 constexpr int kMaxPush = 12, kMaxPushPeers = 6;
-struct PushSeg { const double* src; double* dst; int n; };
+struct PushSeg { const void* src; void* dst; int n; };           // n elements of the launch's element type
 struct PushArgs {
     PushSeg s[kMaxPush]; int ns;
     unsigned* ticket;                 // arrival counter of this launch's workgroups, 0 between launches
@@ -249,12 +249,13 @@ struct PushArgs {
 // The announcement rides on the launch itself: every workgroup makes its stores visible at system scope (release fence), takes a
 // ticket, and the last one stores the sequence number into the neighbours' halo words -- one hop less than a stream-ordered
 // hipStreamWriteValue64 behind the launch (~2 us of blit launch on the path update -> neighbour's next stencil).
+template <typename E>
 __global__ __launch_bounds__(kBlock) void k_push(const PushArgs a) {
     for (int k = 0; k < a.ns; ++k) {
         PushSeg s = a.s[0];
 #pragma unroll
         for (int j = 1; j < kMaxPush; ++j) if (j == k) s = a.s[j];
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < s.n; i += gridDim.x * kBlock) s.dst[i] = s.src[i];
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < s.n; i += gridDim.x * kBlock) ((E*)s.dst)[i] = ((const E*)s.src)[i];
     }
     __threadfence_system();
     __syncthreads();
@@ -300,7 +301,7 @@ struct TeamPart {
     std::vector<long long> send_off, recv_off;            // column messages: offset in send_cols / recv_cols
     std::vector<int> halo_from, halo_to;                  // distinct neighbour ranks
     ColArgs pack{}, unpack{};
-    PushArgs push{};
+    PushArgs push{}, push32{};                            // the fp64 residual's messages; the fp32 residual's (same cells, 4-byte elements, row slabs)
     unsigned* push_ticket = nullptr;
     bool split = false;                                   // interior / edge launches (the part has neighbours)
     hipEvent_t ev_recA = nullptr, ev_gA = nullptr, ev_redge = nullptr, ev_recB = nullptr, ev_gB = nullptr, ev_halo = nullptr;
@@ -331,6 +332,8 @@ struct mi355cg_team_s {
     int rec_mode = REC_EVENTS, wait_mode = WAIT_KERNEL, halo_mode = HALO_LOCAL;
     u64 budget_ticks = 0;                   // what a kernel may wait for a record (100 MHz ticks)
     double timeout_s = 30.0;
+    int dtype = MI355CG_F64;                // MI355CG_F32_MIXED: solves are fp64 refinement around an fp32 inner CG (mi355cg_team_set_dtype)
+    bool f32 = false;                       // the CG loop now running works on the parts' fp32 vectors (an inner solve of F32_MIXED)
     bool broken = false;                    // a solve was abandoned: the ranks' sequence numbers may differ, no further solves
     // Interior / edge launches per phase (the halo travels while the interior items run) or ONE launch per phase.
     bool split_phases = false;
@@ -395,6 +398,7 @@ void team_free(mi355cg_team_s* t) {
     for (auto& p : t->parts) {
         if (p.c) hipSetDevice(p.c->device);
         if (p.slab) ipc_pool().release(p.slab);
+        if (p.c && p.c->rf == (float*)p.c->r) p.c->rf = nullptr;           // F32_MIXED: an alias of r
         if (p.r_pooled && p.c) { ipc_pool().release(p.c->r); p.c->r = nullptr; }
         if (p.side) { hipStreamSynchronize(p.side); hipStreamDestroy(p.side); }
         for (void* q : {(void*)p.send_cols, (void*)p.push_ticket, (void*)p.pll[0], (void*)p.pll[1], (void*)p.dst_self[0], (void*)p.dst_self[1], (void*)p.dst_all[0], (void*)p.dst_all[1],
@@ -432,6 +436,11 @@ Geom part_geom(const GridParams& gp, const Box& bx) {
 }
 double* seg_ptr_g(const Geom& g, double* v, const Seg& s) { return v + (row_off(g, s.y0) - g.base0 + s.x0); }
 double* seg_ptr(const mi355cg_ctx* c, double* v, const Seg& s) { return seg_ptr_g(c->g, v, s); }
+// The residual vector the halo is about, by element size: the fp64 one, or the fp32 one of an inner solve of F32_MIXED -- which lives
+// in the SAME memory (a part's rf is its r reinterpreted: half of it is used), so every neighbour's mapping of r serves both.
+inline int halo_esz(const mi355cg_team_s* t) { return t->f32 ? 4 : 8; }
+void* seg_bytes_g(const Geom& g, void* v, const Seg& s, int esz) { return (char*)v + (size_t)esz * (size_t)(row_off(g, s.y0) - g.base0 + s.x0); }
+void* seg_bytes(const mi355cg_ctx* c, void* v, const Seg& s, int esz) { return seg_bytes_g(c->g, v, s, esz); }
 
 int upload_ptrs(u64*** dev, const std::vector<u64*>& v) {
     HIPCK(hipMalloc((void**)dev, sizeof(u64*) * std::max<size_t>(v.size(), 1)));
@@ -524,32 +533,37 @@ int team_build_tables(mi355cg_team_s* t) {
             if (int rc = upload_ptrs(&p.flag_all[ph], flags)) return rc;
             p.ndst_all = (int)all.size();
         }
-        // PUSH: every outgoing message as (source in this part, destination in the neighbour's memory)
-        p.push = PushArgs{};
-        bool reach = true;
-        for (size_t i = 0; i < p.sends.size(); ++i) {
-            const Seg& s = p.sends[i];
-            if (!p.peer_cols[s.dst] || !p.peer_r[s.dst]) { reach = false; break; }
-            if (p.push.ns >= kMaxPush) return fail(MI355CG_ERR_INVALID, "too many halo messages for one push launch");
-            PushSeg ps{};
-            ps.n = (int)seg_count(s);
-            if (s.kind == 0) {                                             // a row: straight into the neighbour's ghost row
-                ps.src = seg_ptr(p.c, p.c->r, s); ps.dst = seg_ptr_g(t->geoms[s.dst], p.peer_r[s.dst], s);
-            } else {                                                       // a column: packed, into the neighbour's receive buffer where IT expects the message
-                const PartLists Lq = part_lists(t->segs, s.dst);
-                long long off = -1;
-                for (size_t j = 0; j < Lq.recvs.size(); ++j) if (Lq.recvs[j].id == s.id) off = Lq.recv_off[j];
-                if (off < 0) return fail(MI355CG_ERR_STATE, "halo message %d has no receiver", s.id);
-                ps.src = p.send_cols + p.send_off[i]; ps.dst = p.peer_cols[s.dst] + off;
+        // PUSH: every outgoing message as (source in this part, destination in the neighbour's memory); a second list for the fp32
+        // residual of an F32_MIXED inner solve (rows only: the fp32 kernels run on row slabs)
+        for (int f32 = 0; f32 < 2; ++f32) {
+            PushArgs& pa = f32 ? p.push32 : p.push;
+            const int esz = f32 ? 4 : 8;
+            pa = PushArgs{};
+            bool reach = true;
+            for (size_t i = 0; i < p.sends.size(); ++i) {
+                const Seg& s = p.sends[i];
+                if (!p.peer_cols[s.dst] || !p.peer_r[s.dst] || (f32 && s.kind != 0)) { reach = false; break; }
+                if (pa.ns >= kMaxPush) return fail(MI355CG_ERR_INVALID, "too many halo messages for one push launch");
+                PushSeg ps{};
+                ps.n = (int)seg_count(s);
+                if (s.kind == 0) {                                             // a row: straight into the neighbour's ghost row
+                    ps.src = seg_bytes(p.c, p.c->r, s, esz); ps.dst = seg_bytes_g(t->geoms[s.dst], p.peer_r[s.dst], s, esz);
+                } else {                                                       // a column: packed, into the neighbour's receive buffer where IT expects the message
+                    const PartLists Lq = part_lists(t->segs, s.dst);
+                    long long off = -1;
+                    for (size_t j = 0; j < Lq.recvs.size(); ++j) if (Lq.recvs[j].id == s.id) off = Lq.recv_off[j];
+                    if (off < 0) return fail(MI355CG_ERR_STATE, "halo message %d has no receiver", s.id);
+                    ps.src = p.send_cols + p.send_off[i]; ps.dst = p.peer_cols[s.dst] + off;
+                }
+                pa.s[pa.ns++] = ps;
             }
-            p.push.s[p.push.ns++] = ps;
-        }
-        if (!reach) p.push.ns = -1;
-        p.push.ticket = p.push_ticket;
-        p.push.nflag = 0;
-        if (reach) for (int j : p.halo_to) {
-            if (p.push.nflag >= kMaxPushPeers) return fail(MI355CG_ERR_INVALID, "a part pushes its halo to at most %d neighbours", kMaxPushPeers);
-            p.push.flag[p.push.nflag++] = p.peer_mbox[j] + ml.halo(p.rank);
+            if (!reach) pa.ns = -1;
+            pa.ticket = p.push_ticket;
+            pa.nflag = 0;
+            if (reach) for (int j : p.halo_to) {
+                if (pa.nflag >= kMaxPushPeers) return fail(MI355CG_ERR_INVALID, "a part pushes its halo to at most %d neighbours", kMaxPushPeers);
+                pa.flag[pa.nflag++] = p.peer_mbox[j] + ml.halo(p.rank);
+            }
         }
     }
     return MI355CG_OK;
@@ -672,17 +686,18 @@ int part_halo_in(mi355cg_team_s* t, TeamPart& p);
 // RCCL: this rank's messages of one exchange as ONE group on stream hs.  An error inside the group still closes it.
 int rccl_halo_group(mi355cg_team_s* t, TeamPart& p, ncclComm_t comm, hipStream_t hs) {
     RcclApi* api = rccl_api();
+    const int esz = halo_esz(t);
     NCCLCK(api->GroupStart());
     ncclResult_t first = ncclSuccess;
     for (size_t i = 0; i < p.sends.size() && first == ncclSuccess; ++i) {
         const Seg& s = p.sends[i];
-        const double* src = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.send_cols + p.send_off[i];
-        first = api->Send(src, (size_t)seg_count(s), ncclDouble, s.dst, comm, hs);
+        const void* src = s.kind == 0 ? seg_bytes(p.c, p.c->r, s, esz) : (void*)(p.send_cols + p.send_off[i]);
+        first = api->Send(src, (size_t)seg_count(s), s.kind == 0 && t->f32 ? ncclFloat : ncclDouble, s.dst, comm, hs);
     }
     for (size_t i = 0; i < p.recvs.size() && first == ncclSuccess; ++i) {
         const Seg& s = p.recvs[i];
-        double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
-        first = api->Recv(dst, (size_t)seg_count(s), ncclDouble, s.src, comm, hs);
+        void* dst = s.kind == 0 ? seg_bytes(p.c, p.c->r, s, esz) : (void*)(p.recv_cols + p.recv_off[i]);
+        first = api->Recv(dst, (size_t)seg_count(s), s.kind == 0 && t->f32 ? ncclFloat : ncclDouble, s.src, comm, hs);
     }
     const ncclResult_t end = api->GroupEnd();
     if (first != ncclSuccess) return fail(MI355CG_ERR_HIP, "ncclSend/ncclRecv failed: %s", api->GetErrorString(first));
@@ -719,9 +734,10 @@ int part_push_halo(mi355cg_team_s* t, TeamPart& p, u64 seq) {
     const MboxLayout ml{t->world};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.c->stream); }
-    PushArgs a = p.push;
+    PushArgs a = t->f32 ? p.push32 : p.push;
     a.flag_value = seq;
-    hipLaunchKernelGGL(k_push, dim3(32), dim3(kBlock), 0, p.c->stream, a);
+    if (t->f32) hipLaunchKernelGGL(k_push<float>, dim3(32), dim3(kBlock), 0, p.c->stream, a);
+    else hipLaunchKernelGGL(k_push<double>, dim3(32), dim3(kBlock), 0, p.c->stream, a);
     (void)ml;
     if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.c->stream); p.comm_pairs.push_back({e0, e1}); } }
     return MI355CG_OK;
@@ -744,14 +760,15 @@ int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 s
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
     const bool ev = halo_uses_events(t);
+    const bool two = p.split && t->split_phases && !t->f32;             // interior launch, then the edge launch behind the halo (fp64 only)
     if (int rc = part_wait_records(t, p, 1, seqB)) return rc;
-    if (p.split && !t->split_phases) {                                  // one launch: the halo has to be there first
+    if (p.split && !two) {                                               // one launch: the halo has to be there first
         if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
         if (int rc = part_wait_halo(t, p, seqB)) return rc;
     }
     prof_begin(c, &e0);
     const FlagSpec fl = team_flag_spec(t, p, 0, seq);
-    if (p.split && t->split_phases) {
+    if (two) {
         launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->interior, 0}, team_gsrc(t, p, 1, seqB), &fl);
         prof_end(c, 0, e0);
         if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
@@ -760,6 +777,10 @@ int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 s
         launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 1, seqB), &fl);
         prof_end(c, 0, e0);
         team_reduce(t, p, 0, c->interior.grid + c->edge.grid, seq);
+    } else if (t->f32) {                                                 // an inner solve of F32_MIXED: the fp32 kernels on 256-column strips
+        launch_iteration_stencil<float, 4>(c, cfg, c->rf, c->pf, Where{c->stream, &c->whole32, 0}, team_gsrc(t, p, 1, seqB), &fl);
+        prof_end(c, 0, e0);
+        team_reduce(t, p, 0, c->whole32.grid, seq);
     } else {
         launch_iteration_stencil<double, 2>(c, cfg, c->r, c->p, whole_part(c), team_gsrc(t, p, 1, seqB), &fl);
         prof_end(c, 0, e0);
@@ -773,10 +794,11 @@ int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 se
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
     const bool ev = halo_uses_events(t);
+    const bool two = p.split && t->split_phases && !t->f32;
     if (int rc = part_wait_records(t, p, 0, seq)) return rc;
     prof_begin(c, &e0);
     const FlagSpec fl = team_flag_spec(t, p, 1, seq);
-    if (p.split && t->split_phases) {
+    if (two) {
         launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, Where{c->stream, &c->edge, c->interior.grid}, team_gsrc(t, p, 0, seq), &fl);
         if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
         prof_end(c, 1, e0);
@@ -787,10 +809,11 @@ int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 se
         prof_end(c, 1, e0);
         team_reduce(t, p, 1, c->interior.grid + c->edge.grid, seq);
     } else {
-        launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0, seq), &fl);
+        if (t->f32) launch_iteration_update<float, 4>(c, cfg, c->xf, c->rf, c->pf, (const float*)nullptr, Where{c->stream, &c->whole32, 0}, team_gsrc(t, p, 0, seq), &fl);
+        else launch_iteration_update<double, 2>(c, cfg, c->x, c->r, c->p, c->u, whole_part(c), team_gsrc(t, p, 0, seq), &fl);
         prof_end(c, 1, e0);
-        team_reduce(t, p, 1, c->whole.grid, seq);
-        if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
+        team_reduce(t, p, 1, t->f32 ? c->whole32.grid : c->whole.grid, seq);
+        if (p.pack.ns && !t->f32) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
         if (ev) HIPCK(hipEventRecord(p.ev_redge, c->stream));
         if (int rc = part_push_halo(t, p, seq)) return rc;
     }
@@ -806,11 +829,12 @@ int part_halo_in(mi355cg_team_s* t, TeamPart& p) {
         for (auto& o : t->parts) if (o.rank == s.src) q = &o;
         if (!q) return fail(MI355CG_ERR_STATE, "part %d is not in this process", s.src);
         if (s.src != last_src) { HIPCK(hipStreamWaitEvent(p.comm, q->ev_redge, 0)); last_src = s.src; }
-        const double* src = nullptr;
-        if (s.kind == 0) src = seg_ptr(q->c, q->c->r, s);
+        const int esz = s.kind == 0 ? halo_esz(t) : 8;
+        const void* src = nullptr;
+        if (s.kind == 0) src = seg_bytes(q->c, q->c->r, s, esz);
         else for (size_t j = 0; j < q->sends.size(); ++j) if (q->sends[j].id == s.id) src = q->send_cols + q->send_off[j];
-        double* dst = s.kind == 0 ? seg_ptr(p.c, p.c->r, s) : p.recv_cols + p.recv_off[i];
-        HIPCK(hipMemcpyAsync(dst, src, sizeof(double) * seg_count(s), hipMemcpyDefault, p.comm));
+        void* dst = s.kind == 0 ? seg_bytes(p.c, p.c->r, s, esz) : (void*)(p.recv_cols + p.recv_off[i]);
+        HIPCK(hipMemcpyAsync(dst, src, (size_t)esz * seg_count(s), hipMemcpyDefault, p.comm));
     }
     if (p.unpack.ns) { ColArgs a = p.unpack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, p.comm, a); }
     HIPCK(hipEventRecord(p.ev_halo, p.comm));
@@ -959,6 +983,7 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     if (prm->rule != MI355CG_RULE_MSG_MAXNORM && prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "unknown rule %d", prm->rule);
     if (prm->diagnostics) return fail(MI355CG_ERR_INVALID, "per-iteration diagnostics are not available on a team");
     if (t->broken) return fail(MI355CG_ERR_STATE, "this team abandoned an earlier solve and cannot be used again");
+    if (t->f32 && (prm->rule != MI355CG_RULE_REL_2NORM || prm->use_true_solution)) return fail(MI355CG_ERR_INVALID, "the fp32 inner CG runs the REL_2NORM rule without a true solution");
     const bool msg = prm->rule == MI355CG_RULE_MSG_MAXNORM;
     const IterCfg cfg = make_cfg(prm);             // has_u: u is read on every iteration here (the single-GPU path skips it where unobservable)
     const auto t0 = std::chrono::steady_clock::now();
@@ -982,6 +1007,18 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         // one pass over the owned range (mi355cg_solve does the same); the ghost cells of the first direction are zeroed too:
         // they still hold the neighbours' last direction of the previous solve.  Row slabs: the two ghost rows; 2-D parts: the
         // whole vector (ghost columns are strided); a part that is the whole grid has no ghost cells.
+        int nslots = c->whole.grid;
+        if (t->f32) {
+            // an inner solve of F32_MIXED (as inner_cg_f32): rf -- in r's memory -- holds its right-hand side; correction, direction
+            // ring and A p start from zero; one flat pass measures r0 and writes the fresh state
+            const size_t bytes = sizeof(float) * c->storage_len;
+            HIPCK(hipMemsetAsync(c->xf, 0, bytes, c->stream));
+            for (int k = 0; k < c->xsteps; ++k) HIPCK(hipMemsetAsync(c->pf[k], 0, bytes, c->stream));
+            HIPCK(hipMemsetAsync(c->apf, 0, bytes, c->stream));
+            c->cur = 0;
+            launch_update_flat<float, 4>(c, cfg, c->xf, c->rf, c->pf[0], c->apf, (const float*)nullptr, c->stream, c->whole32.grid);
+            nslots = c->whole32.grid;
+        } else {
         if (c->is_slab && c->has_gc) HIPCK(hipMemsetAsync(c->p[0], 0, sizeof(double) * c->storage_len, c->stream));
         else if (c->is_slab) {
             const Geom& g = c->g;
@@ -998,9 +1035,10 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
             if (cfg.has_u) hipLaunchKernelGGL((k_init_fresh<double, 2, true>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
             else hipLaunchKernelGGL((k_init_fresh<double, 2, false>), dim3(c->whole.grid), dim3(kBlock), 0, c->stream, f);
         }
-        if (p.pack.ns) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
+        }
+        if (p.pack.ns && !t->f32) { ColArgs a = p.pack; a.v = c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, c->stream, a); }
         if (ev) HIPCK(hipEventRecord(p.ev_redge, c->stream));
-        team_record(t, p, 1, c->whole.grid, seq_init);
+        team_record(t, p, 1, nslots, seq_init);
         if (int rc = part_push_halo(t, p, seq_init)) return rc;
         HIPCK(hipGetLastError());
         c->solved = true;
@@ -1112,7 +1150,8 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
         if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));                       // the last halo exchange writes this part's ghost cells
         if (int rc = part_wait_halo(t, p, seqB)) return rc;                               // (PUSH: the neighbours' last push has landed before anything else touches r)
         c->cur = fin.it % c->xsteps;
-        if (cfg.x2) launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, c->stream);
+        if (cfg.x2 && t->f32) launch_flush_x<float, 4>(c, c->whole32, c->xf, c->pf, fin, c->stream);
+        else if (cfg.x2) launch_flush_x<double, 2>(c, c->whole, c->x, c->p, fin, c->stream);
         HIPCK(hipGetLastError());
     }
     for (auto& p : t->parts) {
@@ -1151,9 +1190,180 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     return MI355CG_OK;
 }
 
+// ---- F32_MIXED on a team (BASELINE config 3 across GPUs): fp64 iterative refinement around the team's CG loop on fp32 vectors --------
+// The algorithm is solve_mixed's (mi355cg.hip), statement for statement; what a team adds is the halo of x before the fp64 operator
+// apply and a sum over the parts for the residual norm.  There is no reference twin (the reference is fp64 only).
+
+// One exchange of the residual vector's ghost cells outside the CG loop (its sequence number is spent on the halo alone).
+int team_halo_now(mi355cg_team_s* t) {
+    const u64 seq = ++t->seq;
+    const bool ev = halo_uses_events(t);
+    for (auto& p : t->parts) {
+        HIPCK(hipSetDevice(p.c->device));
+        if (p.pack.ns) { ColArgs a = p.pack; a.v = p.c->r; hipLaunchKernelGGL(k_cols, dim3(16), dim3(kBlock), 0, p.c->stream, a); }
+        if (ev) HIPCK(hipEventRecord(p.ev_redge, p.c->stream));
+        if (int rc = part_push_halo(t, p, seq)) return rc;
+    }
+    if (int rc = team_exchange_halo(t, seq)) return rc;
+    for (auto& p : t->parts) {
+        HIPCK(hipSetDevice(p.c->device));
+        if (ev) HIPCK(hipStreamWaitEvent(p.c->stream, p.ev_halo, 0));
+        if (int rc = part_wait_halo(t, p, seq)) return rc;
+    }
+    return MI355CG_OK;
+}
+// every rank: the sum over all parts of one number per part, added in part order (the same bits on every rank).  Also a meeting
+// point: when it returns, every rank has finished what it did before calling it.
+int team_sum(mi355cg_team_s* t, const std::vector<double>& mine, double* total) {
+    std::vector<double> all(t->world, 0.0);
+    if (t->rccl && t->world > 1) { if (int rc = boot_all_gather(t, mine.data(), all.data(), sizeof(double))) return rc; }
+    else for (size_t i = 0; i < t->parts.size(); ++i) all[t->parts[i].rank] = mine[i];
+    double s = 0.0;
+    for (double v : all) s += v;
+    *total = s;
+    return MI355CG_OK;
+}
+
+// every part's compute stream has drained, on every rank
+int team_meet(mi355cg_team_s* t, const char* what) {
+    for (auto& p : t->parts) {
+        HIPCK(hipSetDevice(p.c->device));
+        const int rc = bounded_sync(t, p.c->stream, nullptr, t->timeout_s);
+        if (rc < 0) return team_abandon(t, what);
+        if (rc) return rc;
+    }
+    std::vector<double> one(t->parts.size(), 1.0);
+    double n = 0;
+    return team_sum(t, one, &n);
+}
+
+int team_solve_mixed(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
+                     const volatile int* stop_flag, mi355cg_results* out) {
+    if (prm->rule != MI355CG_RULE_REL_2NORM) return fail(MI355CG_ERR_INVALID, "F32_MIXED offers the REL_2NORM rule only");
+    if (t->broken) return fail(MI355CG_ERR_STATE, "this team abandoned an earlier solve and cannot be used again");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (int rc = team_pick_modes(t)) return rc;
+    for (auto& p : t->parts) if (t->halo_mode == HALO_PUSH && p.push32.ns < 0) return fail(MI355CG_ERR_STATE, "push halo: a neighbour's memory is not mapped");
+    const double inner_eps = prm->inner_eps > 0 ? prm->inner_eps : 1e-4;
+    const int rgrid = 1024;
+    // rf = (float)(b - ap) on every part (into r's memory: the fp64 residual is not kept between the stages), *norm = ||b - ap||_2 over the team.
+    // The sum is a meeting point of the ranks: nobody's next halo message can land in ghost cells this pass is still writing.
+    auto residual_pass = [&](double* norm) -> int {
+        std::vector<double> mine(t->parts.size(), 0.0);
+        for (auto& p : t->parts) {
+            mi355cg_ctx* c = p.c;
+            HIPCK(hipSetDevice(c->device));
+            hipLaunchKernelGGL(k_residual_to_f32, dim3(rgrid), dim3(kBlock), 0, c->stream, c->storage_len, c->g.own_begin, c->g.own_len, c->b, c->ap, c->rf, c->partR);
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(c->partR_h, c->partR, sizeof(double) * rgrid, hipMemcpyDeviceToHost, c->stream));
+        }
+        for (size_t i = 0; i < t->parts.size(); ++i) {
+            mi355cg_ctx* c = t->parts[i].c;
+            HIPCK(hipSetDevice(c->device));
+            const int rc = bounded_sync(t, c->stream, nullptr, t->timeout_s);
+            if (rc < 0) return team_abandon(t, "a part's stream did not drain (residual pass)");
+            if (rc) return rc;
+            double s = 0; for (int k = 0; k < rgrid; ++k) s += c->partR_h[k];
+            mine[i] = s;
+        }
+        double total = 0;
+        if (int rc = team_sum(t, mine, &total)) return rc;
+        *norm = std::sqrt(total);
+        return MI355CG_OK;
+    };
+    for (auto& p : t->parts) {
+        mi355cg_ctx* c = p.c;
+        HIPCK(hipSetDevice(c->device));
+        const size_t bytes64 = sizeof(double) * c->storage_len;
+        HIPCK(hipMemsetAsync(c->x, 0, bytes64, c->stream));
+        HIPCK(hipMemsetAsync(c->ap, 0, bytes64, c->stream));
+    }
+    double bnorm = 0, rnorm = 0;
+    if (int rc = residual_pass(&bnorm)) return rc;       // x = 0: r = b
+    rnorm = bnorm;
+    int total = 0, outer = 0;
+    bool interrupted = false, converged = bnorm == 0.0;
+    double loop_s = 0;
+    while (!converged && total < prm->max_iterations && !interrupted) {
+        mi355cg_params ip = *prm;
+        ip.eps_rel = inner_eps; ip.diagnostics = 0; ip.use_true_solution = 0; ip.callback_every = 0;
+        ip.max_iterations = prm->max_iterations - total;              // restarted refinement: every inner solve starts from scratch with the remaining budget
+        mi355cg_results ir{};
+        t->f32 = true;
+        const int rc_in = team_solve(t, &ip, nullptr, nullptr, stop_flag, &ir);
+        t->f32 = false;
+        if (rc_in) return rc_in;
+        const int its = ir.iterations;
+        interrupted = ir.stop_reason == MI355CG_STOP_INTERRUPTED;
+        loop_s += ir.loop_seconds;
+        total += its; ++outer;
+        for (auto& p : t->parts) {
+            mi355cg_ctx* c = p.c;
+            HIPCK(hipSetDevice(c->device));
+            hipLaunchKernelGGL(k_accumulate_f32, dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->x, c->xf);
+            // The halo machinery is about the residual vector: x travels as its guest.  ALL of it is copied: r's memory held the fp32
+            // residual until now, and the operator reads zeros in the boundary rows, the pads and the columns outside the domain.
+            HIPCK(hipMemcpyAsync(c->r, c->x, sizeof(double) * c->storage_len, hipMemcpyDeviceToDevice, c->stream));
+        }
+        // (the copy also clears the ghost cells, so no neighbour may have delivered yet: meet first)
+        if (int rc = team_meet(t, "the copy of x")) return rc;
+        if (int rc = team_halo_now(t)) return rc;
+        for (auto& p : t->parts) {
+            HIPCK(hipSetDevice(p.c->device));
+            launch_apply<double, 2>(p.c, p.c->r, p.c->ap, whole_part(p.c));
+        }
+        const double prev = rnorm;
+        if (int rc = residual_pass(&rnorm)) return rc;
+        if (cb) cb(user, total, 0.0, rnorm, 0.0);
+        converged = !prm->fixed_iterations && rnorm <= prm->eps_rel * bnorm;
+        if (prm->fixed_iterations || its == 0) break;
+        if (!converged && rnorm > 0.5 * prev) break;      // fp32 cannot improve this x any further
+    }
+    // leave the fp64 residual of the returned x in r (mi355cg_team_get_vector(1))
+    for (auto& p : t->parts) {
+        mi355cg_ctx* c = p.c;
+        HIPCK(hipSetDevice(c->device));
+        HIPCK(hipMemsetAsync(c->r, 0, sizeof(double) * c->storage_len, c->stream));      // (boundary rows and pads held fp32 data: the fp64 kernels read zeros there)
+        hipLaunchKernelGGL((k_sub<double>), dim3(flat_grid(c->g.own_len)), dim3(kBlock), 0, c->stream, c->g.own_begin, c->g.own_len, c->b, c->ap, c->r);
+        HIPCK(hipGetLastError());
+        const int rc = bounded_sync(t, c->stream, nullptr, t->timeout_s);
+        if (rc < 0) return team_abandon(t, "a part's stream did not drain (end of the mixed solve)");
+        if (rc) return rc;
+        c->solved = true; c->cur = 0;
+    }
+    // nobody's next solve may write ghost cells a slower rank's last pass still reads
+    if (int rc = team_meet(t, "the end of the mixed solve")) return rc;
+    mi355cg_results res{};
+    res.iterations = total; res.converged = converged ? 1 : 0;
+    res.stop_reason = interrupted ? MI355CG_STOP_INTERRUPTED : (converged ? MI355CG_STOP_RESIDUAL : MI355CG_STOP_ITERATIONS);
+    res.final_residual_norm = res.final_precision = res.final_error_norm = DBL_MAX;
+    res.r_norm2 = rnorm; res.initial_r_norm2 = bnorm;
+    res.refine_outer = outer; res.refine_true_rel = bnorm > 0 ? rnorm / bnorm : 0.0;
+    res.solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    res.loop_seconds = loop_s;
+    if (out) *out = res;
+    return MI355CG_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// MI355CG_F32_MIXED: the team's solves become fp64 iterative refinement around an fp32 inner CG (mi355cg_create's dtype, for a team;
+// BASELINE config 3 across GPUs).  Row slabs only: the fp32 kernels march 256-column strips.  Collective: every rank makes the same call.
+int mi355cg_team_set_dtype(mi355cg_team t, int dtype) {
+    if (!t) return fail(MI355CG_ERR_INVALID, "null team");
+    if (dtype != MI355CG_F64 && dtype != MI355CG_F32_MIXED) return fail(MI355CG_ERR_INVALID, "unknown dtype %d", dtype);
+    if (dtype == MI355CG_F32_MIXED) {
+        for (auto& p : t->parts) {
+            HIPCK(hipSetDevice(p.c->device));
+            if (int rc = ensure_f32_vectors(p.c)) return rc;
+            p.c->rf = (float*)p.c->r;                    // the fp32 residual lives in the fp64 residual's memory: see seg_bytes
+        }
+    }
+    t->dtype = dtype;
+    return MI355CG_OK;
+}
 
 int mi355cg_decompose(int n, int world, int decomp, int rank, int* y_lo, int* y_hi, int* x_lo, int* x_hi) {
     GridParams gp;
@@ -1409,6 +1619,7 @@ void mi355cg_team_destroy(mi355cg_team t) { team_free(t); }
 int mi355cg_team_solve(mi355cg_team t, const mi355cg_params* prm, mi355cg_iter_cb cb, void* user,
                        const volatile int* stop_flag, mi355cg_results* out) {
     if (!t || !prm) return fail(MI355CG_ERR_INVALID, "null argument");
+    if (t->dtype == MI355CG_F32_MIXED) return team_solve_mixed(t, prm, cb, user, stop_flag, out);
     return team_solve(t, prm, cb, user, stop_flag, out);
 }
 

@@ -466,6 +466,14 @@ class Team:
             raise ValueError(f"expected {self.size} entries, got {v.size}")
         _capi.check(self._lib.mi355cg_team_set_vector(self._h, which, v))
 
+    def set_dtype(self, dtype: int):
+        """_capi.F32_MIXED: the team's solves become fp64 iterative refinement around an fp32 inner CG (REL_2NORM only, row slabs
+        only) -- BASELINE config 3 across GPUs; _capi.F64 switches back.  Collective: every rank makes the same call."""
+        rc = self._lib.mi355cg_team_set_dtype(self._h, dtype)
+        if rc == _capi.ERR_INVALID:
+            raise ValueError(self._lib.mi355cg_last_error().decode())
+        _capi.check(rc)
+
     def checksum(self, which: int):
         o = (C.c_double * 2)()
         _capi.check(self._lib.mi355cg_team_checksum(self._h, which, o))

@@ -336,3 +336,47 @@ def test_local_team_with_mailboxes_and_pushed_halo(n, world, decomp, monkeypatch
     assert (rm.iterations, rm.stop_reason, rm.final_residual_norm, rm.final_precision) == (r0.iterations, r0.stop_reason, r0.final_residual_norm, r0.final_precision)
     assert cbs == cb0 and np.array_equal(t.vector(0), s0._handle.solution())
     t.close()
+
+
+@pytest.mark.parametrize("n,world,env", [(256, 2, {}), (514, 3, {}), (1026, 4, {}), (258, 5, {"MI355CG_TEAM_RECORDS": "mailbox", "MI355CG_TEAM_HALO": "push"}),
+                                         (514, 3, {"MI355CG_TEAM_THREADS": "1"})])
+def test_team_mixed_precision_is_the_single_gpu_mixed_solve(n, world, env, monkeypatch):
+    """BASELINE config 3's algorithm on a team of row slabs (mi355cg_team_set_dtype): the fp32 CG loop runs across the parts (halo rows
+    of 4-byte elements in the residual vector's memory), the fp64 refinement steps exchange the halo of x.  Same inner iterations, same
+    outer steps, the same x bit for bit as the single-GPU F32_MIXED solve; then the team is an fp64 team again."""
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    from oracle.oracle import OracleGrid
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    kw = dict(eps_rel=1e-8, max_iterations=10 ** 6)
+    s1 = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    cb1 = []
+    r1 = s1._handle.solve(_params(isa, 1, **kw), callback=lambda *a: cb1.append(a))
+    t = Team.local(n, world, 0)
+    t.set_dtype(isa.F32_MIXED)
+    cbs = []
+    rt = t.solve(_params(isa, 1, **kw), callback=lambda *a: cbs.append(a))
+    assert (rt.iterations, rt.converged, rt.stop_reason, rt.refine_outer) == (r1.iterations, 1, r1.stop_reason, r1.refine_outer) and rt.refine_outer >= 2
+    assert [c[0] for c in cbs] == [c[0] for c in cb1]                      # the inner solves end after the same iterations
+    assert np.allclose([c[2] for c in cbs], [c[2] for c in cb1], rtol=1e-10, atol=0)
+    x = t.vector(0)
+    assert np.array_equal(x, s1._handle.solution())
+    assert abs(rt.r_norm2 - r1.r_norm2) <= 1e-12 * r1.initial_r_norm2
+    if n <= 514:
+        og = OracleGrid(n, n)
+        b = og.rhs()
+        assert np.linalg.norm(b - og.apply(x)) <= 1e-8 * np.linalg.norm(b)            # the fp64 true residual by the oracle's operator
+        r = t.vector(1)                                                             # ... and the team left b - A x in r
+        assert np.abs(r - (b - og.apply(x))).max() <= 1e-12 * np.abs(b).max()
+    with pytest.raises(ValueError):
+        t.solve(_params(isa, 0, max_iterations=10))                                 # F32_MIXED: REL_2NORM only
+    t.set_dtype(isa.F64)
+    s64, r64, _ = _single(isa, n, 1, eps_rel=1e-8, max_iterations=10 ** 5)
+    r2 = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 5))
+    assert (r2.iterations, r2.r_norm2) == (r64.iterations, r64.r_norm2) and np.array_equal(t.vector(0), s64._handle.solution())
+    t.close()
+    t2 = Team.local(258, 4, 1)
+    with pytest.raises(ValueError):
+        t2.set_dtype(isa.F32_MIXED)                                                 # a 2 x 2 cut has no 256-column strips
+    t2.close()

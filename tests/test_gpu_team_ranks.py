@@ -102,6 +102,15 @@ def _worker(rank, world, port, n, decomp, modes, outdir):
                 step = "(5) the team still solves after all that"
                 r = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=37, fixed_iterations=1))
                 out[f"{mode}/fixed"] = np.array([r.iterations, r.r_norm2])
+                if decomp == 0:
+                    step = "(6) F32_MIXED on the team (row slabs): fp64 refinement around the fp32 CG loop, halo messages of 4-byte elements"
+                    t.set_dtype(isa.F32_MIXED)
+                    r = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 6))
+                    out[f"{mode}/mixed"] = np.array([r.iterations, r.converged, r.stop_reason, r.refine_outer, r.r_norm2, r.initial_r_norm2])
+                    out[f"{mode}/xmixed"] = t.vector(0)
+                    t.set_dtype(isa.F64)
+                    r = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=37, fixed_iterations=1))
+                    out[f"{mode}/fixed2"] = np.array([r.iterations, r.r_norm2])
                 step = "close"
                 t.close()
                 dist.barrier()
@@ -137,7 +146,9 @@ def _reference(n):
     msg = s._handle.solve(_params(isa, 0, **MSG), callback=lambda *a: cbs.append(a))
     xm = s._handle.solution()
     fixed = s._handle.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=37, fixed_iterations=1))
-    return dict(rel=rel, x=x, cs=cs, msg=msg, cbs=np.array(cbs, dtype=float).reshape(-1, 4), xm=xm, fixed=fixed)
+    s32 = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    mixed = s32._handle.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 6))
+    return dict(rel=rel, x=x, cs=cs, msg=msg, cbs=np.array(cbs, dtype=float).reshape(-1, 4), xm=xm, fixed=fixed, mixed=mixed, xmixed=s32._handle.solution())
 
 
 def _check(parts, ref, world, modes):
@@ -167,6 +178,17 @@ def _check(parts, ref, world, modes):
             assert tuple(p[f"{mode}/stop0"]) == (1, 0, 4), (mode, rank, p[f"{mode}/stop0"])     # the flag was up before iteration 1: its record carries it
             assert tuple(p[f"{mode}/stop1"]) == tuple(parts[0][f"{mode}/stop1"]) and p[f"{mode}/stop1"][2] == 4 and 1 <= p[f"{mode}/stop1"][0] <= 3, (mode, rank, p[f"{mode}/stop1"])
             assert tuple(p[f"{mode}/fixed"]) == (37, ref["fixed"].r_norm2), (mode, rank)
+        if f"{mode}/mixed" in parts[0]:
+            xx = np.full_like(ref["x"], np.nan)
+            for rank, p in enumerate(parts):
+                it, conv, reason, outer, rn, r0 = p[f"{mode}/mixed"]
+                m = ref["mixed"]
+                assert (it, conv, reason, outer) == (m.iterations, m.converged, m.stop_reason, m.refine_outer) and conv == 1, (mode, rank, p[f"{mode}/mixed"])
+                assert abs(rn - m.r_norm2) <= 1e-12 * m.initial_r_norm2 and abs(r0 - m.initial_r_norm2) <= 1e-13 * m.initial_r_norm2      # (block sums added part by part)
+                own = ~np.isnan(p[f"{mode}/xmixed"])
+                xx[own] = p[f"{mode}/xmixed"][own]
+                assert tuple(p[f"{mode}/fixed2"]) == (37, ref["fixed"].r_norm2), (mode, rank)           # and fp64 again afterwards
+            assert np.array_equal(xx, ref["xmixed"]), mode                       # the single-GPU mixed solve's x, bit for bit
         assert np.array_equal(x, ref["x"]), mode                                # every unknown, the single-context bits
         assert np.array_equal(xm, ref["xm"]), mode
         cs = np.sum([p[f"{mode}/cs"] for p in parts], axis=0)
