@@ -14,7 +14,8 @@ RHS (the reference's f and Dirichlet data), x0 = 0, convergence tests disabled s
 
 N > 1 (and MI355CG_BENCH_DIST=1 at N = 1): the measurement is a sequence of LEGS, each a fresh set of N rank processes (one per
 GPU) started by a coordinator that never touches a GPU itself: the order-safe RCCL schedule first, then the mailbox + push
-transport, then sub-records (two-stream RCCL halo, config 5 strong, config 4's 2 x 2 at N = 4, one process driving N devices).
+transport without and with the interior / edge split, then sub-records (config 5 strong, config 4's 2 x 2 at N = 4, two-stream
+RCCL halo, one process driving N devices).
 A leg that stalls is killed at its own time limit and noted; the legs that finished are never lost.  `value` = the best leg of
 the requested configuration that passed its cross-check against one GPU; every leg is in `legs`.
 
@@ -120,6 +121,8 @@ TRANSPORTS = {
     "mailbox+push": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "auto"},
                      "records: a one-workgroup reducer launch beside the producer stores them straight into every OTHER rank's IPC-mapped mailbox; the consumer launch reduces its own partials and polls only for the others; "
                      "halo: pushed into the neighbours' ghost cells by one small launch + a stream-ordered flag (RCCL only bootstraps)"),
+    "mailbox+push+split": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "auto", "MI355CG_TEAM_SPLIT": "1"},
+                           "as mailbox+push, with north_star's overlap: every phase is an interior launch and an edge launch, the halo travels (and is waited for) between them"),
     "rccl-stream": ({"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "stream", "MI355CG_TEAM_IPC": "0"},
                     "records: ncclAllGather on the compute stream, halo: ncclSend/ncclRecv on a second stream + second communicator"),
     "mailbox+rccl-halo": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "inline"},
@@ -133,11 +136,13 @@ def plan_legs(args):
     base = {"scaling": args.scaling, "decomp": args.decomp, "grid": args.n, "driver": "ranks"}
     legs = [dict(base, name="rccl-inline", transport="rccl-inline", headline=True),
             dict(base, name="mailbox+push", transport="mailbox+push", headline=True),
-            dict(base, name="rccl-stream", transport="rccl-stream", headline=False)]
+            dict(base, name="mailbox+push+split", transport="mailbox+push+split", headline=True)]
+    # sub-records: BASELINE's own configurations first, then the other transports
     if not (args.scaling == "strong" and args.n == 32768):
         legs.append(dict(base, name="config5-strong-32768", transport="mailbox+push", headline=False, scaling="strong", grid=32768, decomp="rows", verify=0))
     if N == 4 and not (args.decomp == "2d" and args.scaling == "strong" and args.n == 16384):
         legs.append(dict(base, name="config4-2x2-16384", transport="mailbox+push", headline=False, scaling="strong", grid=16384, decomp="2d"))
+    legs.append(dict(base, name="rccl-stream", transport="rccl-stream", headline=False))
     if N > 1:          # last: in the torchrun form only rank 0's coordinator runs it, while the others are already done
         legs.append(dict(base, name="local-one-process", transport="local", headline=False, driver="local"))
     if args.legs == "default":
