@@ -575,13 +575,21 @@ int team_build_tables(mi355cg_team_s* t) {
 // behind them run, miss their records within their own budget and end the solve), and the solve returns MI355CG_ERR_STATE.
 int bounded_sync(mi355cg_team_s* t, hipStream_t st, const volatile int* stop_flag, double seconds) {
     const auto t0 = std::chrono::steady_clock::now();
+    bool patient = false;
     for (unsigned spins = 0;; ++spins) {
         if (stop_flag && *stop_flag) *t->stop_h = 1;
         const hipError_t q = hipStreamQuery(st);
         if (q == hipSuccess) return MI355CG_OK;
         if (q != hipErrorNotReady) HIPCK(q);
-        if ((spins & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) return -1;
-        if (stop_flag) std::this_thread::yield(); else if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        // The first 20 ms are spent polling (a 20-iteration solve at N = 4096 is 2.7 ms: a sleep of 50 us that turns into 100 with the
+        // scheduler's help would be 4 % of it); a wait that lasts longer does not care about 50 us and gives the core away.
+        double waited = -1.0;
+        if ((spins & 255u) == 255u) {
+            waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > seconds) return -1;
+            if (waited > 0.02) patient = true;
+        }
+        if (stop_flag || !patient) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
 int team_abandon(mi355cg_team_s* t, const char* what) {
