@@ -204,6 +204,12 @@ def run_leg_child(spec, args):
         # and before it enters the closing barrier (a gloo barrier over TCP costs 0.2 - 1 ms, a tenth of a 20-iteration window and
         # no part of the solve); the job's time is the maximum over the ranks.
         barrier()
+        if not local and world > 1:
+            # (untimed) a gloo barrier over TCP lets the ranks go up to a millisecond apart -- a third of a 20-iteration window, which
+            # the ranks that left first would spend waiting for the last one's records.  A one-iteration solve aligns them: its last
+            # records are a barrier on the devices, and every host sees its own copy within microseconds.
+            run(1)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         res = run(args.steps)
         torch.cuda.synchronize()
