@@ -20,3 +20,11 @@ for world in [int(w) for w in (sys.argv[2] if len(sys.argv) > 2 else "1,2,3").sp
     x = t.vector(0)
     print("team", world, rt.iterations, rt.converged, rt.refine_outer, [(c[0], c[2]) for c in cbs], "x equal:", np.array_equal(x, s1._handle.solution()), flush=True)
     t.close()
+import time
+for world in (5,):
+    t = Team.local(130, world, 0)
+    t.set_dtype(isa.F32_MIXED)
+    t0 = time.time(); rt = t.solve(p); print("local world", world, "N=130 mixed:", rt.iterations, rt.refine_outer, f"{time.time() - t0:.3f} s", flush=True)
+    t.set_dtype(isa.F64)
+    t0 = time.time(); rt = t.solve(p); print("local world", world, "N=130 fp64:", rt.iterations, f"{time.time() - t0:.3f} s", flush=True)
+    t.close()
