@@ -87,16 +87,27 @@ def cpu_baseline(n: int, iters: int):
            "sample": f"{iters} CG iterations of oracle/cg_oracle.c (MatrixFreeSolver loop without the "
                      f"diagnostic second apply) at N={n}, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
     try:        # the same loop on every host core (OpenMP build of the same source; BASELINE.md section 4 "ref-omp")
-        from oracle.oracle import mf_solve_all_cores
-        t0 = time.perf_counter()
-        mf_solve_all_cores(n, b, 0.0, 3)                                # calibration: keep this leg to about 10 s
-        per_it = (time.perf_counter() - t0) / 3
+        from oracle.oracle import host_cpu_share, mf_solve_all_cores
+        # How many threads?  A GPU box shows all of the host's logical CPUs and grants a share of them (16 per GPU): one thread per
+        # visible CPU is throttled to a crawl.  Candidates: the cgroup's quota where it can be read, and a few fixed counts; two
+        # iterations each, the fastest one is then timed for about 10 s.
+        visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cands = sorted({min(visible, c) for c in (host_cpu_share(), 8, 16, 32, 64, visible)})
+        trials = {}
+        mf_solve_all_cores(n, b, 0.0, 1, cands[0])                      # (library load, page faults of the first call)
+        for th in cands:
+            t0 = time.perf_counter()
+            mf_solve_all_cores(n, b, 0.0, 2, th)
+            trials[th] = (time.perf_counter() - t0) / 2
+        best = min(trials, key=trials.get)
+        per_it = trials[best]
         k = max(3, min(10 * iters, int(10.0 / max(per_it, 1e-4))))
         t0 = time.perf_counter()
-        its, _, threads = mf_solve_all_cores(n, b, 0.0, k)
+        its, _, threads = mf_solve_all_cores(n, b, 0.0, k, best)
         dt2 = time.perf_counter() - t0
-        out["all_cores"] = {"value": its / dt2, "unit": "iters/s", "cores": threads, "kind": "port-openmp",
-                            "sample": f"{its} iterations, {dt2:.1f} s, {threads} OpenMP threads"}
+        out["all_cores"] = {"value": its / dt2, "unit": "iters/s", "cores": threads, "cpu_quota": host_cpu_share(), "kind": "port-openmp",
+                            "sample": f"{its} iterations, {dt2:.1f} s, {threads} OpenMP threads ({visible} logical CPUs visible; seconds per iteration by thread count: "
+                                      + ", ".join(f"{th}: {trials[th]:.3f}" for th in cands) + ")"}
     except Exception as e:                                           # never fail the bench on the baseline leg
         out["all_cores"] = {"error": repr(e)[:200]}
     return out

@@ -450,6 +450,7 @@ void og_mixed_solve(const og_grid *g, const double *b, double eps, int max_itera
 #ifdef _OPENMP
 #include <omp.h>
 int og_omp_threads(void) { return omp_get_max_threads(); }
+void og_omp_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 static void og_apply_row(const og_grid *g, int yi, const double *x, double *y)
 {

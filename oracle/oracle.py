@@ -253,6 +253,8 @@ def lib_omp():
         L.og_rhs.argtypes = [GP, _DP]
         L.og_rhs.restype = None
         L.og_omp_threads.restype = C.c_int
+        L.og_omp_set_threads.argtypes = [C.c_int]
+        L.og_omp_set_threads.restype = None
         L.og_mf_solve_omp.argtypes = [GP, _DP, C.c_double, C.c_int, _DP]
         L.og_mf_solve_omp.restype = C.c_int
         L.og_apply_omp.argtypes = [GP, _DP, _DP]
@@ -261,9 +263,34 @@ def lib_omp():
     return _lib_omp
 
 
-def mf_solve_all_cores(n: int, b: np.ndarray, eps: float, max_iterations: int):
-    """(iterations, x, threads): the MatrixFreeSolver loop on every host core."""
+def host_cpu_share() -> int:
+    """CPUs this process may really use: the affinity mask, cut to the cgroup's CPU quota (a GPU box shows all of the host's
+    logical CPUs but grants a share of them; one OpenMP thread per VISIBLE CPU would spend its time being throttled)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, math.ceil(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, math.ceil(quota / int(f.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def mf_solve_all_cores(n: int, b: np.ndarray, eps: float, max_iterations: int, threads: int = 0):
+    """(iterations, x, threads): the MatrixFreeSolver loop on every host core this process has (threads = 0: host_cpu_share())."""
     L = lib_omp()
+    L.og_omp_set_threads(threads if threads > 0 else host_cpu_share())
     g = _Grid()
     L.og_grid_init(C.byref(g), n, n, 1.0, 2.0, 1.0, 2.0)
     x = np.empty(g.size)
