@@ -16,7 +16,7 @@ KNOBS = {
     "MI355CG_ITEM_ROWS": ["1", "2", "3", "5", "7", "13", "32", "64", "200", "100000"],
     "MI355CG_WAVES": ["256", "512", "1024", "2048", "3072"],
     "MI355CG_BLOCKS": ["8", "24", "37", "100", "256", "512"],
-    "MI355CG_DEPTH": ["2", "3"],
+    "MI355CG_DEPTH": ["2", "3"], "MI355CG_DYN_ROWS": ["0", "1", "2", "5", "16"],
     "MI355CG_XSTEPS": ["2", "4", "8"],
     "MI355CG_XCD_CLASSES": ["0", "1"],
 }

@@ -14,7 +14,7 @@ from iterative_solvers_amd import _capi
 from iterative_solvers_amd.distributed import Team
 
 TEAM_KNOBS = {"MI355CG_TEAM_SPLIT": ["0", "1"], "MI355CG_TEAM_THREADS": ["0", "1"], "MI355CG_ITEM_ROWS": ["1", "3", "16", "100000"],
-              "MI355CG_DEPTH": ["2", "3"], "MI355CG_XSTEPS": ["2", "4"]}
+              "MI355CG_DEPTH": ["2", "3"], "MI355CG_DYN_ROWS": ["0", "1", "2", "5", "16"], "MI355CG_XSTEPS": ["2", "4"]}
 
 
 def params(rule, iters):
