@@ -983,6 +983,12 @@ int team_pick_modes(mi355cg_team_s* t) {
         (void)several_devices;
     }
     for (auto& p : t->parts) if (t->halo_mode == HALO_PUSH && p.push.ns < 0) return fail(MI355CG_ERR_STATE, "push halo: a neighbour's memory is not mapped");
+    // WAIT_KERNEL: a consumer launch fills the CUs with workgroups that poll for the OTHER parts' records, and those parts wait for
+    // THIS part's reducer launch -- which therefore has to become resident beside the consumer: 72 VGPRs per wave next to two consumer
+    // waves per SIMD (192 each in the fp64 default launches, 216 in the fp32 ones: 128 / 80 of 512 left).  The 12-word update of MI355CG_XSTEPS=8 takes 264: no room,
+    // the reducer would wait for a wave that never ends.  Those teams let their streams wait instead.
+    if (t->rec_mode == REC_MAILBOX && t->wait_mode == WAIT_KERNEL && wait_env != 1)
+        for (auto& p : t->parts) if (p.c->xsteps > 4) t->wait_mode = WAIT_STREAM;
     return MI355CG_OK;
 }
 
