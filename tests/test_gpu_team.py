@@ -380,3 +380,33 @@ def test_team_mixed_precision_is_the_single_gpu_mixed_solve(n, world, env, monke
     with pytest.raises(ValueError):
         t2.set_dtype(isa.F32_MIXED)                                                 # a 2 x 2 cut has no 256-column strips
     t2.close()
+
+
+@pytest.mark.parametrize("n,world,decomp", [(1026, 2, 0), (1026, 4, 1), (2050, 8, 0)])
+def test_local_team_across_several_gpus(n, world, decomp):
+    """One process, one GPU per part (peer access over xGMI, one host thread per part, kernels polling their mailboxes): runs wherever
+    the box has the GPUs; the one-GPU test box skips it."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    import iterative_solvers_amd as isa
+    from iterative_solvers_amd.distributed import Team
+    kw = dict(eps_rel=1e-8, max_iterations=10 ** 5)
+    s1, r1, _ = _single(isa, n, 1, **kw)
+    t = Team.local(n, world, decomp, devices=list(range(world)))
+    d = t.describe()
+    assert (d["records"], d["wait"]) == ("mailbox", "kernel")
+    rt = t.solve(_params(isa, 1, **kw))
+    assert (rt.iterations, rt.r_norm2) == (r1.iterations, r1.r_norm2) and np.array_equal(t.vector(0), s1._handle.solution())
+    kw = dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iterations=10 ** 5)
+    s0, r0, cb0 = _single(isa, n, 0, **kw)
+    cbs = []
+    rm = t.solve(_params(isa, 0, **kw), callback=lambda *a: cbs.append(a))
+    assert (rm.iterations, rm.stop_reason) == (r0.iterations, r0.stop_reason) and cbs == cb0 and np.array_equal(t.vector(0), s0._handle.solution())
+    if decomp == 0:
+        t.set_dtype(isa.F32_MIXED)
+        s32 = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+        r32 = s32._handle.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 6))
+        rt = t.solve(_params(isa, 1, eps_rel=1e-8, max_iterations=10 ** 6))
+        assert (rt.iterations, rt.refine_outer) == (r32.iterations, r32.refine_outer) and np.array_equal(t.vector(0), s32._handle.solution())
+    t.close()

@@ -55,8 +55,10 @@ MSG = dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iter
 
 def _worker(rank, world, port, n, decomp, modes, outdir):
     sys.path.insert(0, ROOT)
-    from tests import nccl_shim
-    os.environ["MI355CG_RCCL_LIB"] = nccl_shim.build()
+    real = os.environ.get("MI355CG_TEST_REAL_RCCL") == "1"             # one GPU per rank and librccl itself (boxes with several GPUs)
+    if not real:
+        from tests import nccl_shim
+        os.environ["MI355CG_RCCL_LIB"] = nccl_shim.build()
     os.environ["NCCL_SHIM_TIMEOUT_MS"] = "60000"
     os.environ["MI355CG_TEAM_TIMEOUT_MS"] = "20000"
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -67,7 +69,8 @@ def _worker(rank, world, port, n, decomp, modes, outdir):
     try:
         import iterative_solvers_amd as isa
         from iterative_solvers_amd.distributed import Team
-        torch.cuda.set_device(0)
+        dev = rank if real else 0
+        torch.cuda.set_device(dev)
         step = "start"
         for mode in modes:
             try:
@@ -76,7 +79,7 @@ def _worker(rank, world, port, n, decomp, modes, outdir):
                 os.environ.update(MODES[mode])
                 step = "create"
                 t_mode = time.time()
-                t = Team.rccl(n, decomp, device=0)
+                t = Team.rccl(n, decomp, device=dev)
                 d = t.describe()
                 out[f"{mode}/desc"] = np.array([d["records"], d["wait"], d["halo"], str(d["split"]), str(d["ipc"]), str(d["shared_device"]), str(d["rccl_nranks"]), d["rccl_lib"], d["ipc_note"]])
                 step = "(1) REL_2NORM to convergence"
@@ -156,7 +159,7 @@ def _reference(n):
     return dict(rel=rel, x=x, cs=cs, msg=msg, cbs=np.array(cbs, dtype=float).reshape(-1, 4), xm=xm, fixed=fixed, mixed=mixed, xmixed=s32._handle.solution())
 
 
-def _check(parts, ref, world, modes):
+def _check(parts, ref, world, modes, real=False):
     for mode in modes:
         rec, halo, split = EXPECT[mode]
         x = np.full_like(ref["x"], np.nan)
@@ -164,8 +167,11 @@ def _check(parts, ref, world, modes):
         for rank, p in enumerate(parts):
             d = p[f"{mode}/desc"]
             assert (d[0], d[2], int(d[3])) == (rec, halo, split), (mode, d)
-            assert d[1] == ("kernel" if "kernel-wait" in mode else "stream") and int(d[5]) == 1     # the ranks found out that they share one GPU: no polling kernels unless asked for
-            assert int(d[4]) == (0 if mode == "no-ipc" else 1) and int(d[6]) == world and d[7].endswith("libnccl_shim.so")
+            if real:
+                assert d[1] == "kernel" and int(d[5]) == 0 and int(d[6]) == world and d[7].startswith("librccl")     # a GPU each: kernels poll, RCCL is RCCL
+            else:
+                assert d[1] == ("kernel" if "kernel-wait" in mode else "stream") and int(d[5]) == 1     # the ranks found out that they share one GPU: no polling kernels unless asked for
+                assert int(d[4]) == (0 if mode == "no-ipc" else 1) and int(d[6]) == world and d[7].endswith("libnccl_shim.so")
             it, conv, reason, rn, r0 = p[f"{mode}/rel"]
             assert (it, conv, reason) == (ref["rel"].iterations, ref["rel"].converged, ref["rel"].stop_reason), (mode, rank)
             assert rn == ref["rel"].r_norm2 and r0 == ref["rel"].initial_r_norm2, (mode, rank)
@@ -211,3 +217,21 @@ def test_rank_processes_reproduce_the_single_context(world, n, decomp, modes):
     ref = _reference(n)
     parts = _run(world, n, decomp, modes)
     _check(parts, ref, world, modes)
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("world,n,decomp", [(2, 1026, 0), (4, 1026, 1), (8, 2050, 0)])
+def test_rank_processes_on_gpus_of_their_own_over_real_rccl(world, n, decomp, monkeypatch):
+    """The same scenarios with one GPU per rank and librccl itself: runs wherever the box has the GPUs (the one-GPU test box skips it).
+    Every transport combination, kernels polling their mailboxes (the default when no two ranks share a device)."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_gpus()}")
+    monkeypatch.setenv("MI355CG_TEST_REAL_RCCL", "1")
+    modes = [m for m in MODES if "kernel-wait" not in m]
+    ref = _reference(n)
+    parts = _run(world, n, decomp, modes)
+    _check(parts, ref, world, modes, real=True)
