@@ -1016,13 +1016,13 @@ __global__ __launch_bounds__(kBlock) void k_update(const UpdateArgs<T> a) {
         const long long j0 = i, j1 = i + stride;
         const vec_t xa = X[j0], pa = Pp[j0], ra = R[j0], qa = Q[j0];
         const vec_t xb = X[j1], pb = Pp[j1], rb = R[j1], qb = Q[j1];
-        vec_t ua, ub; if (HAS_U) { ua = Uu[j0]; ub = Uu[j1]; }
+        vec_t ua{}, ub{}; if (HAS_U) { ua = Uu[j0]; ub = Uu[j1]; }
         elem(j0, xa, pa, ra, qa, ua);
         elem(j1, xb, pb, rb, qb, ub);
     }
     if (i < end) {
         const vec_t x0 = X[i], pv = Pp[i], r0 = R[i], qv = Q[i];
-        vec_t uv; if (HAS_U) uv = Uu[i];
+        vec_t uv{}; if (HAS_U) uv = Uu[i];
         elem(i, x0, pv, r0, qv, uv);
     }
 

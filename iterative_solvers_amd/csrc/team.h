@@ -434,8 +434,6 @@ Geom part_geom(const GridParams& gp, const Box& bx) {
     build_geom(&c, 2, bx.y_lo, bx.y_hi);
     return c.g;
 }
-double* seg_ptr_g(const Geom& g, double* v, const Seg& s) { return v + (row_off(g, s.y0) - g.base0 + s.x0); }
-double* seg_ptr(const mi355cg_ctx* c, double* v, const Seg& s) { return seg_ptr_g(c->g, v, s); }
 // The residual vector the halo is about, by element size: the fp64 one, or the fp32 one of an inner solve of F32_MIXED -- which lives
 // in the SAME memory (a part's rf is its r reinterpreted: half of it is used), so every neighbour's mapping of r serves both.
 inline int halo_esz(const mi355cg_team_s* t) { return t->f32 ? 4 : 8; }
