@@ -3,7 +3,8 @@
 kernels plus the single host thread's driving cost -- a rehearsal of the decomposition, not a scaling measurement):
   config 4: N = 16384, 2 x 2, REL_2NORM to 1e-8 (full solve) against the single-context solve of the same grid
   config 5: N = 32768, 8 parts (4 x 2) and 8 row slabs, a fixed number of iterations
-Usage: python tools/team_config_runs.py [4|5] [iters5]"""
+  config 3 on a team: N = 8192, F32_MIXED, 4 row slabs, full solve against the single-GPU F32_MIXED solve
+Usage: python tools/team_config_runs.py [3|4|5] [iters5]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,7 +29,23 @@ def params(**kw):
     return p
 
 
-if which == "4":
+if which == "3":
+    n, kw = 8192, dict(eps_rel=1e-8, max_iterations=10 ** 6)
+    t = Team.local(n, 4, _capi.DECOMP_ROWS)
+    t.set_dtype(isa.F32_MIXED)
+    t0 = time.perf_counter(); r = t.solve(params(**kw)); dt = time.perf_counter() - t0
+    out = {"config": "3 on a team: 8192 F32_MIXED, 4 row slabs, LOCAL team on one GPU, rel2 1e-8", "iterations": r.iterations, "outer_steps": r.refine_outer, "converged": bool(r.converged),
+           "true_rel_residual": r.refine_true_rel, "seconds": round(dt, 2), "checksum_x": list(t.checksum(0))}
+    print(json.dumps(out), flush=True)
+    t.close()
+    s = isa.MatrixFreeSystem(n, n, 1.0, 2.0, 1.0, 2.0, dtype=isa.F32_MIXED)
+    t0 = time.perf_counter(); r1 = s._handle.solve(params(**kw)); dt = time.perf_counter() - t0
+    one = {"config": "3: the same grid on the single context", "iterations": r1.iterations, "outer_steps": r1.refine_outer, "converged": bool(r1.converged),
+           "true_rel_residual": r1.refine_true_rel, "seconds": round(dt, 2), "iters_per_sec": round(r1.iterations / dt, 1), "checksum_x": cs(s._handle, 0)}
+    print(json.dumps(one), flush=True)
+    print(json.dumps({"config3_team_equals_single_context": {"iterations_and_outer_steps": (out["iterations"], out["outer_steps"]) == (one["iterations"], one["outer_steps"]),
+                                                             "x_bit_for_bit": out["checksum_x"] == one["checksum_x"]}}), flush=True)
+elif which == "4":
     n, kw = 16384, dict(eps_rel=1e-8, max_iterations=10 ** 6)
     t = Team.local(n, 4, _capi.DECOMP_2D)
     t0 = time.perf_counter(); r = t.solve(params(**kw)); dt = time.perf_counter() - t0
