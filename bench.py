@@ -134,6 +134,8 @@ TRANSPORTS = {
                      "halo: pushed into the neighbours' ghost cells by one small launch + a stream-ordered flag (RCCL only bootstraps)"),
     "mailbox+push+split": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "auto", "MI355CG_TEAM_SPLIT": "1"},
                            "as mailbox+push, with north_star's overlap: every phase is an interior launch and an edge launch, the halo travels (and is waited for) between them"),
+    "mailbox+push+split-update": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "auto", "MI355CG_TEAM_SPLIT": "2"},
+                                  "as mailbox+push, with only the update phase in two launches: the edge rows are updated and pushed first, so the neighbours' rows are there when the next stencil launch -- ONE launch -- is due"),
     "rccl-stream": ({"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "stream", "MI355CG_TEAM_IPC": "0"},
                     "records: ncclAllGather on the compute stream, halo: ncclSend/ncclRecv on a second stream + second communicator"),
     "mailbox+rccl-halo": ({"MI355CG_TEAM_RECORDS": "auto", "MI355CG_TEAM_HALO": "inline"},
@@ -147,6 +149,7 @@ def plan_legs(args):
     base = {"scaling": args.scaling, "decomp": args.decomp, "grid": args.n, "driver": "ranks"}
     legs = [dict(base, name="rccl-inline", transport="rccl-inline", headline=True),
             dict(base, name="mailbox+push", transport="mailbox+push", headline=True),
+            dict(base, name="mailbox+push+split-update", transport="mailbox+push+split-update", headline=True),
             dict(base, name="mailbox+push+split", transport="mailbox+push+split", headline=True)]
     # sub-records: BASELINE's own configurations first, then the other transports
     if not (args.scaling == "strong" and args.n == 32768):

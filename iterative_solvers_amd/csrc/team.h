@@ -336,7 +336,7 @@ struct mi355cg_team_s {
     bool f32 = false;                       // the CG loop now running works on the parts' fp32 vectors (an inner solve of F32_MIXED)
     bool broken = false;                    // a solve was abandoned: the ranks' sequence numbers may differ, no further solves
     // Interior / edge launches per phase (the halo travels while the interior items run) or ONE launch per phase.
-    bool split_phases = false;
+    int split_phases = 0;                   // 0: one launch per phase; 1: interior / edge launches in both phases; 2: in the update phase only
     bool profiling = false;
     double prof_kernel_ms = 0, prof_comm_ms = 0, prof_wall_ms = 0;     // per iteration, last profiled solve
     int hub_device = 0;
@@ -766,7 +766,7 @@ int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 s
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
     const bool ev = halo_uses_events(t);
-    const bool two = p.split && t->split_phases && !t->f32;             // interior launch, then the edge launch behind the halo (fp64 only)
+    const bool two = p.split && t->split_phases == 1 && !t->f32;        // interior launch, then the edge launch behind the halo (fp64 only)
     if (int rc = part_wait_records(t, p, 1, seqB)) return rc;
     if (p.split && !two) {                                               // one launch: the halo has to be there first
         if (ev) HIPCK(hipStreamWaitEvent(c->stream, p.ev_halo, 0));
@@ -800,7 +800,9 @@ int part_update_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 se
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
     const bool ev = halo_uses_events(t);
-    const bool two = p.split && t->split_phases && !t->f32;
+    // (split_phases == 2: only this phase is split -- the edge items' rows leave ~60 us before the phase ends, so the neighbours'
+    //  rows are there when the next stencil launch, ONE launch, is due; one more launch per iteration instead of two)
+    const bool two = p.split && t->split_phases >= 1 && !t->f32;
     if (int rc = part_wait_records(t, p, 0, seq)) return rc;
     prof_begin(c, &e0);
     const FlagSpec fl = team_flag_spec(t, p, 1, seq);
@@ -956,7 +958,7 @@ int team_pick_modes(mi355cg_team_s* t) {
     const int wait_env = env_choice("MI355CG_TEAM_WAIT", {"auto", "kernel", "stream"}, 0);
     int halo_env = env_choice("MI355CG_TEAM_HALO", {"auto", "inline", "stream", "push"}, 0);
     if (halo_env == 0 && env_int("MI355CG_TEAM_HALO_INLINE", 0)) halo_env = 1;
-    t->split_phases = env_int("MI355CG_TEAM_SPLIT", 0) != 0;
+    t->split_phases = std::min(2, std::max(0, env_int("MI355CG_TEAM_SPLIT", 0)));
     t->timeout_s = std::max(1, env_int("MI355CG_TEAM_TIMEOUT_MS", 30000)) * 1e-3;
     t->budget_ticks = (u64)(t->timeout_s * 1e8);
     if (t->rccl) {
@@ -969,7 +971,7 @@ int team_pick_modes(mi355cg_team_s* t) {
         t->halo_mode = halo_env == 1 ? HALO_RCCL_INLINE : halo_env == 2 ? HALO_RCCL_STREAM : halo_env == 3 ? HALO_PUSH : ((t->ipc_ok || solo) ? HALO_PUSH : HALO_RCCL_INLINE);
         if (t->halo_mode == HALO_PUSH && !(t->ipc_ok || solo)) return fail(MI355CG_ERR_STATE, "MI355CG_TEAM_HALO=push: the ranks could not map each other's vectors (IPC)");
         if (t->halo_mode == HALO_RCCL_STREAM && !solo && !t->comm_halo) return fail(MI355CG_ERR_STATE, "MI355CG_TEAM_HALO=stream needs the second communicator (create the team with MI355CG_TEAM_HALO=stream set)");
-        if (t->split_phases && t->halo_mode == HALO_RCCL_INLINE) t->split_phases = false;      // nothing to overlap with
+        if (t->split_phases && t->halo_mode == HALO_RCCL_INLINE) t->split_phases = 0;      // nothing to overlap with
     } else {
         // one process: parts that share a GPU order their streams with events (a kernel that polls would keep the producer off the
         // CUs); parts on GPUs of their own poll their mailboxes -- no hub stream, no event joins on the critical path
@@ -1621,7 +1623,7 @@ int mi355cg_team_describe(mi355cg_team t, char* buf, int len) {
     if (!t || !buf || len <= 0) return fail(MI355CG_ERR_INVALID, "null argument");
     if (int rc = team_pick_modes(t)) return rc;
     std::snprintf(buf, (size_t)len, "transport=%s records=%s wait=%s halo=%s split=%d ipc=%d shared_device=%d rccl_nranks=%d rccl_lib=%s ipc_note=%s",
-                  t->rccl ? "rccl" : "local", rec_name(t->rec_mode), wait_name(t->wait_mode), halo_name(t->halo_mode), t->split_phases ? 1 : 0,
+                  t->rccl ? "rccl" : "local", rec_name(t->rec_mode), wait_name(t->wait_mode), halo_name(t->halo_mode), t->split_phases,
                   t->ipc_ok ? 1 : 0, t->shared_device ? 1 : 0, t->rccl_nranks, t->rccl && rccl_api() ? rccl_api()->lib_name.c_str() : "-", t->ipc_note.c_str());
     return MI355CG_OK;
 }

@@ -34,7 +34,7 @@ def test_legs_of_an_eight_gpu_run():
     legs = bench.plan_legs(_args())
     names = [l["name"] for l in legs]
     assert names[:2] == ["rccl-inline", "mailbox+push"]                 # the order-safe schedule is timed first
-    assert [l["name"] for l in legs if l["headline"]] == ["rccl-inline", "mailbox+push", "mailbox+push+split"]
+    assert [l["name"] for l in legs if l["headline"]] == ["rccl-inline", "mailbox+push", "mailbox+push+split-update", "mailbox+push+split"]
     assert names.index("config5-strong-32768") < names.index("rccl-stream")          # BASELINE's own configurations before the other transports
     assert "config5-strong-32768" in names and names[-1] == "local-one-process" and "config4-2x2-16384" not in names
     strong = next(l for l in legs if l["name"] == "config5-strong-32768")

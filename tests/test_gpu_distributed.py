@@ -181,11 +181,11 @@ def test_bench_rehearsal_three_ranks_under_torchrun():
     IPC mailboxes and pushed halos between them, every leg cross-checked against one context."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29881",
            os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "40", "--warmup", "5", "--grid", "768", "--repeats", "3",
-           "--legs", "rccl-inline,mailbox+push,mailbox+push+split,rccl-stream,local-one-process"]
+           "--legs", "rccl-inline,mailbox+push,mailbox+push+split-update,mailbox+push+split,rccl-stream,local-one-process"]
     j = _bench_line(cmd, _rehearsal_env())
     assert j["n_gpus"] == 3 and j["rccl_nranks"] == 3 and j["value"] > 0 and "notes" not in j
-    assert list(j["legs"]) == ["rccl-inline", "mailbox+push", "mailbox+push+split", "rccl-stream", "local-one-process"]
-    assert j["legs"]["mailbox+push+split"]["transport"]["split"] == 1 and j["legs"]["mailbox+push"]["transport"]["split"] == 0
+    assert list(j["legs"]) == ["rccl-inline", "mailbox+push", "mailbox+push+split-update", "mailbox+push+split", "rccl-stream", "local-one-process"]
+    assert [j["legs"][k]["transport"]["split"] for k in ("mailbox+push", "mailbox+push+split-update", "mailbox+push+split")] == [0, 2, 1]
     for name, leg in j["legs"].items():
         assert "error" not in leg, leg
         assert leg["verify_against_one_gpu"]["ok"] is True and leg["verify_against_one_gpu"]["bit_identical"] is True

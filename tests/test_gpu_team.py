@@ -110,13 +110,13 @@ def test_local_team_with_one_thread_per_part(n, world, decomp, monkeypatch):
     t.close()
 
 
-@pytest.mark.parametrize("n,world,decomp", [(258, 4, 1), (130, 3, 0)])
-def test_team_with_interior_and_edge_launches(n, world, decomp, monkeypatch):
+@pytest.mark.parametrize("n,world,decomp,split", [(258, 4, 1, "1"), (130, 3, 0, "1"), (258, 4, 1, "2"), (514, 5, 0, "2")])
+def test_team_with_interior_and_edge_launches(n, world, decomp, split, monkeypatch):
     """MI355CG_TEAM_SPLIT=1: the phases as interior + edge launches (the halo travels beside the interior items) instead of the
-    default one launch per phase.  Same bits."""
+    default one launch per phase; = 2: only the update phase (the rows leave early, the stencil stays one launch).  Same bits."""
     import iterative_solvers_amd as isa
     from iterative_solvers_amd.distributed import Team
-    monkeypatch.setenv("MI355CG_TEAM_SPLIT", "1")
+    monkeypatch.setenv("MI355CG_TEAM_SPLIT", split)
     for rule, kw in ((1, dict(eps_rel=1e-8, max_iterations=10 ** 5)),
                      (0, dict(eps_precision=1e-9, eps_residual=1e-9, eps_exact_error=-1.0, max_iterations=10 ** 5))):
         s1, r1, cb1 = _single(isa, n, rule, **kw)

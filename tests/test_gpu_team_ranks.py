@@ -26,6 +26,7 @@ MODES = {
     "rccl+stream+split": {"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "stream", "MI355CG_TEAM_SPLIT": "1"},
     "mailbox+push": {},                                                                              # the default (auto): IPC mailboxes, pushed halo
     "mailbox+push+split": {"MI355CG_TEAM_SPLIT": "1"},
+    "mailbox+push+split-update": {"MI355CG_TEAM_SPLIT": "2"},                                        # only the update phase in two launches: the rows leave early
     "mailbox+inline": {"MI355CG_TEAM_HALO": "inline"},
     "rccl+push": {"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "push"},
     "no-ipc": {"MI355CG_TEAM_IPC": "0"},                                                             # the ranks cannot map each other: falls back to RCCL for both
@@ -34,7 +35,7 @@ MODES = {
 }
 EXPECT = {
     "rccl+inline": ("rccl", "rccl-inline", 0), "rccl+stream": ("rccl", "rccl-stream", 0), "rccl+stream+split": ("rccl", "rccl-stream", 1),
-    "mailbox+push": ("mailbox", "push", 0), "mailbox+push+split": ("mailbox", "push", 1), "mailbox+inline": ("mailbox", "rccl-inline", 0),
+    "mailbox+push": ("mailbox", "push", 0), "mailbox+push+split": ("mailbox", "push", 1), "mailbox+push+split-update": ("mailbox", "push", 2), "mailbox+inline": ("mailbox", "rccl-inline", 0),
     "rccl+push": ("rccl", "push", 0), "no-ipc": ("rccl", "rccl-inline", 0), "mailbox+push+kernel-wait": ("mailbox", "push", 0),
 }
 for _name in filter(None, os.environ.get("MI355CG_TEST_EXTRA_MODES", "").split(",")):      # tools/dbg_modes.py: "mailbox+push#3" = a further run of that mode
