@@ -209,7 +209,7 @@ def _check(parts, ref, world, modes, real=False):
 
 @pytest.mark.parametrize("world,n,decomp,modes", [
     (2, 258, 0, list(MODES)),                                                   # (kernel-wait included: two small launches can share the GPU)
-    (4, 258, 1, [m for m in MODES if "kernel-wait" not in m]),                  # 2 x 2: column messages, packed and unpacked
+    (4, 258, 1, list(MODES)),                                                   # 2 x 2: column messages, packed and unpacked
     (5, 130, 0, ["rccl+inline", "mailbox+push", "rccl+stream+split"]),
     (3, 1026, 0, ["mailbox+push", "rccl+inline", "mailbox+push+kernel-wait"]),      # (polling kernels of three ranks on one GPU: the reducer launches fit beside them)
     (4, 1026, 1, ["mailbox+push", "rccl+stream"]),
