@@ -307,8 +307,11 @@ def leg_command(args, spec, out_path):
 
 def leg_env(base_env, spec, rank, world, local_rank, port):
     env = dict(base_env)
+    rehearsal_wait = env.get("MI355CG_TEAM_WAIT") if env.get("MI355CG_BENCH_ONE_GPU") == "1" else None
     for k in ("MI355CG_TEAM_RECORDS", "MI355CG_TEAM_HALO", "MI355CG_TEAM_IPC", "MI355CG_TEAM_WAIT", "MI355CG_TEAM_SPLIT", "MI355CG_TEAM_HALO_INLINE"):
         env.pop(k, None)
+    if rehearsal_wait:                                  # one-GPU rehearsal of what ranks on GPUs of their own do by default: kernels poll their mailboxes
+        env["MI355CG_TEAM_WAIT"] = rehearsal_wait
     if spec["transport"] in TRANSPORTS:
         env.update(TRANSPORTS[spec["transport"]][0])
     env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(local_rank), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
