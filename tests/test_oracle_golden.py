@@ -142,3 +142,20 @@ def test_mixed_precision_statement_of_the_oracle_converges_in_fp64_terms():
     assert true_rel <= 1e-8 and abs(true_rel - rel) <= 1e-12
     ref = g.mf_solve(eps=1e-10, max_iterations=10 ** 5)
     assert np.abs(x - ref.x).max() <= 1e-6 * np.abs(ref.x).max()
+
+
+def test_all_cores_timing_baseline_takes_the_same_steps_and_knows_its_cpu_share():
+    """bench.py's "all host cores" figure: the OpenMP build of the same loop.  Its inner products are OpenMP reductions, so it is a
+    timing baseline and never a checker -- but it has to run the same iteration: same count to a loose tolerance, x to rounding."""
+    import os
+    from oracle.oracle import OracleGrid, host_cpu_share, mf_solve_all_cores
+    share = host_cpu_share()
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    assert 1 <= share <= visible
+    og = OracleGrid(64, 64)
+    b = og.rhs()
+    ref = og.mf_solve(eps=1e-8, max_iterations=10 ** 4, diagnostics=False)
+    for threads in (1, 2, min(4, share)):
+        its, x, used = mf_solve_all_cores(64, b, 1e-8, 10 ** 4, threads)
+        assert used == threads and abs(its - ref.iterations) <= 1
+        assert np.abs(x - ref.x).max() <= 1e-9 * np.abs(ref.x).max()
