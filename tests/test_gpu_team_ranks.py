@@ -134,7 +134,14 @@ def _run(world, n, decomp, modes):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() * 7 + world * 31 + n) % 1500
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, n, decomp, modes, d), nprocs=world, join=True)
+        ctx = mp.spawn(_worker, args=(world, port, n, decomp, modes, d), nprocs=world, join=False)
+        deadline = time.time() + 300.0                                   # every wait inside is bounded; this is the belt to those braces
+        while not ctx.join(timeout=1.0):
+            if time.time() > deadline:
+                for proc in ctx.processes:                               # exactly the rank processes started above
+                    if proc.is_alive():
+                        proc.kill()
+                pytest.fail(f"rank processes still running after 300 s (world {world}, N {n}, modes {modes})")
         parts = []
         for r in range(world):
             with np.load(os.path.join(d, f"r{r}.npz")) as f:
