@@ -196,9 +196,10 @@ int  mi355cg_dist_halo_recv_counts(mi355cg_handle h, long long *n_from_lo, long 
  * unknown count.  MI355CG_DECOMP_2D: (world/2) x 2 blocks -- BASELINE config 4's "2 x 2" for world = 4: y-cuts where the
  * slabs hold equal unknowns, every slab cut in x where ITS unknowns halve, x-cuts on 128-column strip boundaries.
  * Per iteration every part needs every part's 16-double record of partial sums twice, and its neighbours' boundary rows /
- * columns of the residual once.  Default transport: the producer launch's last block stores the record straight into every
- * part's mailbox (peer memory over xGMI, IPC-mapped across processes) and the consumer launch polls its own mailbox; the
- * halo is pushed into the neighbours' ghost cells by one small launch and announced with a stream-ordered 64-bit write.
+ * columns of the residual once.  Default transport: a one-workgroup reducer launch beside every producer launch stores the part's
+ * record straight into every other part's mailbox (peer memory over xGMI, IPC-mapped across processes); the consumer launch reduces
+ * its own partials and polls its own mailbox for the others; the halo is pushed into the neighbours' ghost cells by one small launch
+ * whose last workgroup announces it with a 64-bit store the neighbour's stream waits for.
  * RCCL (ncclAllGather / ncclSend / ncclRecv) carries the bootstrap and is the fallback for both (environment:
  * MI355CG_TEAM_RECORDS = auto | rccl | mailbox | events, MI355CG_TEAM_WAIT = auto | kernel | stream, MI355CG_TEAM_HALO = auto |
  * inline | stream | push, MI355CG_TEAM_TIMEOUT_MS; mi355cg_team_describe says what a team uses).  Results are bit-identical to

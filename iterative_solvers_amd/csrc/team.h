@@ -16,24 +16,29 @@
 //          This is what a single-process host (the reference's DirichletSolver is one) uses, and what lets one GPU rehearse
 //          an 8-part run bit for bit.
 // How the records travel (mi355cg_team_s::rec_mode):
-//   MAILBOX  the last block of the producer launch stores the record, as 32 flagged 64-bit words, straight into the mailbox of
-//            every part (peer GPU memory over xGMI; IPC-mapped when the part is another process); the consumer launch polls its
-//            own mailbox in its prologue (bounded; WAIT_KERNEL) -- the hop costs one store latency and no launch, collective or
-//            event.  Ranks that share one physical GPU (rehearsals) let their STREAMS wait for an announcement word instead
-//            (hipStreamWaitValue64; WAIT_STREAM), because a polling kernel could keep the producing kernel off the CUs.
+//   MAILBOX  every workgroup of a producer launch also stores its partials as flagged 64-bit words; a one-workgroup REDUCER launch on
+//            a side stream, resident beside the producer, polls them as they arrive and stores the part's record (32 flagged words)
+//            straight into the mailbox of every OTHER part (peer GPU memory over xGMI; IPC-mapped when the part is another process).
+//            A consumer launch reduces its own part's partials itself, as on a single GPU, and polls its own mailbox only for the other
+//            parts' records (bounded; WAIT_KERNEL): the hop costs the reducer's tail (2 - 3 us) + one store latency, and nothing sits
+//            between the producer and the consumer launch on the stream.  Ranks that share one physical GPU (rehearsals) let their
+//            STREAMS wait for an announcement word instead (hipStreamWaitValue64; WAIT_STREAM), because polling consumers of several
+//            ranks could keep each other's producers off the CUs.
 //   RCCL     ncclAllGather of the flagged words on the COMPUTE stream, between producer and consumer launch.
 //   EVENTS   LOCAL teams whose parts share a GPU: direct stores + a hub stream joining the parts' events.
 // How the halo travels (halo_mode):
 //   PUSH         one small launch behind the update launch stores the boundary rows / packed columns into the neighbours' ghost
-//                rows / receive buffers; a stream-ordered 64-bit write (hipStreamWriteValue64) into each neighbour's mailbox
-//                announces them, and the neighbour's compute stream waits for that word before its next stencil launch.
+//                rows / receive buffers; when all its workgroups have released their stores, the last one stores the sequence number
+//                into each neighbour's mailbox, and the neighbour's compute stream waits for that word (hipStreamWaitValue64)
+//                before its next stencil launch.
 //   RCCL_INLINE  one ncclSend/ncclRecv group per iteration on the compute stream (one communicator, one stream: order-safe).
 //   RCCL_STREAM  the same group on a SECOND stream and communicator, ordered with the compute stream by two events.
 //   LOCAL        device-to-device copies on the parts' comm streams (one process).
 // Per iteration and part (default: ONE launch per phase; MI355CG_TEAM_SPLIT=1 cuts each phase into interior + edge launches
-// so that the halo travels beside the interior items instead):
-//     wait halo ; stencil -> record A (last block of the launch) ............ every part's update launch needs all records A
-//     update -> record B ; pack columns ; halo of r ........................... every part's next stencil launch needs all records B
+// so that the halo travels beside the interior items instead, = 2 the update phase only):
+//     wait halo ; stencil (+ reducer -> record A) ............................ every part's update launch needs all records A
+//     update (+ reducer -> record B) ; pack columns ; halo of r ............... every part's next stencil launch needs all records B
+// F32_MIXED (mi355cg_team_set_dtype): the same loop on the parts' fp32 vectors inside fp64 refinement steps (team_solve_mixed).
 // Sums travel as double-double pairs and are reduced in part order by every consumer, so every decomposition takes
 // bit-identical steps (tests/test_gpu_team.py, tests/test_gpu_team_ranks.py).
 #include <dlfcn.h>
@@ -667,7 +672,7 @@ int part_wait_records(mi355cg_team_s* t, TeamPart& p, int which, u64 seq) {
 // after the producers of phase `which` (0 = A, 1 = B) have been enqueued: whatever the transport needs so that every part's
 // compute stream may run the consumer launch
 int team_exchange_records(mi355cg_team_s* t, int which, u64 seq) {
-    if (t->rec_mode == REC_MAILBOX) return MI355CG_OK;                 // the producers' last blocks deliver; the consumers poll (or their streams wait)
+    if (t->rec_mode == REC_MAILBOX) return MI355CG_OK;                 // the reducer launches deliver; the consumers poll (or their streams wait)
     if (t->rec_mode == REC_RCCL) {
         // in-stream: the compute stream itself carries the all-gather between the producer and the consumer launch
         TeamPart& p = t->parts[0];
@@ -761,7 +766,7 @@ bool halo_uses_events(const mi355cg_team_s* t) { return t->halo_mode == HALO_LOC
 
 // ---- one part's share of an iteration (called by the one driving thread, or by the part's own thread) --------------
 // stencil phase of iteration seq: consumes the update records of seq - 1 (seqB) and the halo of r that followed them; the launch
-// that ends it writes the part's record (its last block)
+// that ends it is followed by the part's reducer launch (team_reduce)
 int part_stencil_phase(mi355cg_team_s* t, TeamPart& p, const IterCfg& cfg, u64 seqB, u64 seq) {
     mi355cg_ctx* c = p.c;
     hipEvent_t e0 = nullptr;
