@@ -274,6 +274,8 @@ def run_leg_child(spec, args):
         "transport": desc, "processes": 1 if local else world, "devices_used": min(ndev, nparts) if local else world,
         "hbm_gbps": round(bytes_it * U * its / 1e9, 1), "per_gpu_gbps": round(moved, 1), "per_gpu_frac_of_8000": round(moved / HBM_PEAK_GBPS, 4),
         "phases_ms": phases, "verify_against_one_gpu": verify,
+        # the lead part's two launches alone (HIP events of the profiled pass): what the GPU does while it is not waiting for anybody
+        "kernels_only_gbps_per_gpu": round(bytes_it * U / nparts / (phases["kernels_ms"] * 1e-3) / 1e9, 1) if phases.get("kernels_ms", 0) > 0 else None,
     }
     team.close()
     if not local:
