@@ -1096,7 +1096,14 @@ int team_solve(mi355cg_team_s* t, const mi355cg_params* prm, mi355cg_iter_cb cb,
     // parts of N = 4096, 0.77 vs 0.59 with 8) -- so they keep the one-thread loop.  MI355CG_TEAM_THREADS=0 | 1 overrides.
     bool several_devices = false;
     for (auto& p : t->parts) if (p.c->device != t->parts[0].c->device) several_devices = true;
-    if (!t->rccl && t->parts.size() > 1 && env_int("MI355CG_TEAM_THREADS", several_devices ? 1 : 0) != 0) {
+    // Never with stream-level value waits between parts that share a device: a process's streams are multiplexed onto a few hardware
+    // queues, and a wait at the head of one of them holds back every stream behind it -- the producer of the awaited word too, unless
+    // its packets were enqueued first.  The one-thread loop enqueues in that order; threads do not (seen as a hang inside the runtime
+    // with MI355CG_TEAM_THREADS=1 + mailboxes + pushed halo on one GPU).  Rank processes have queues of their own.
+    bool shares = false;
+    for (auto& a : t->parts) for (auto& b : t->parts) if (&a != &b && a.c->device == b.c->device) shares = true;
+    const bool value_waits = (t->rec_mode == REC_MAILBOX && t->wait_mode == WAIT_STREAM) || t->halo_mode == HALO_PUSH;
+    if (!t->rccl && t->parts.size() > 1 && env_int("MI355CG_TEAM_THREADS", several_devices ? 1 : 0) != 0 && !(shares && value_waits)) {
         crew.reset(new TeamCrew);
         crew->t = t; crew->cfg = cfg; crew->nthreads = (int)t->parts.size();
         for (int i = 1; i < crew->nthreads; ++i) crew_threads.emplace_back([&, i] { crew->worker(i); });

@@ -84,13 +84,18 @@ def test_local_team_msg_rule_callbacks_and_stop_reason(n, world, decomp):
     t.close()
 
 
-@pytest.mark.parametrize("n,world,decomp", [(258, 4, 1), (130, 3, 0), (66, 16, 0)])
-def test_local_team_with_one_thread_per_part(n, world, decomp, monkeypatch):
+@pytest.mark.parametrize("n,world,decomp,mail", [(258, 4, 1, False), (130, 3, 0, False), (66, 16, 0, False), (258, 4, 1, True)])
+def test_local_team_with_one_thread_per_part(n, world, decomp, mail, monkeypatch):
     """The multi-GPU form of the LOCAL transport (a host thread per part, two barriers per iteration), forced on for parts that
-    share the test box's one GPU: same bits as the one-thread loop and as the single context, both rules, 16 threads on few cores."""
+    share the test box's one GPU: same bits as the one-thread loop and as the single context, both rules, 16 threads on few cores.
+    mail: asking for mailboxes + pushed halo as well -- stream-level value waits between parts that share a device, which the threads
+    must not enqueue in their own order (hardware queues are shared): the team falls back to the one-thread loop.  Same bits."""
     import iterative_solvers_amd as isa
     from iterative_solvers_amd.distributed import Team
     monkeypatch.setenv("MI355CG_TEAM_THREADS", "1")
+    if mail:
+        monkeypatch.setenv("MI355CG_TEAM_RECORDS", "mailbox")
+        monkeypatch.setenv("MI355CG_TEAM_HALO", "push")
     kw = dict(eps_rel=1e-8, max_iterations=10 ** 5)
     s1, r1, _ = _single(isa, n, 1, **kw)
     t = Team.local(n, world, decomp)
