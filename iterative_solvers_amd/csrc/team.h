@@ -747,8 +747,14 @@ int part_push_halo(mi355cg_team_s* t, TeamPart& p, u64 seq) {
     if (t->profiling) { e0 = p.c->events.get(); if (e0) hipEventRecord(e0, p.c->stream); }
     PushArgs a = t->f32 ? p.push32 : p.push;
     a.flag_value = seq;
-    if (t->f32) hipLaunchKernelGGL(k_push<float>, dim3(32), dim3(kBlock), 0, p.c->stream, a);
-    else hipLaunchKernelGGL(k_push<double>, dim3(32), dim3(kBlock), 0, p.c->stream, a);
+    // one workgroup per 8 KB, at most 32: every workgroup pays a system-scope release and a ticket, so a launch that moves two 32 KB
+    // rows is quickest with 8 of them (two polling parts on one GPU, N = 4096: 0.1454 ms per iteration with 8, 0.1465 with 4,
+    // 0.1485 - 0.1493 with 32, 0.1484 with 1)
+    long long bytes = 0;
+    for (int k = 0; k < a.ns; ++k) bytes += (long long)a.s[k].n * (t->f32 ? 4 : 8);
+    const int grid = (int)std::min<long long>(32, std::max<long long>(1, (bytes + 8191) / 8192));
+    if (t->f32) hipLaunchKernelGGL(k_push<float>, dim3(grid), dim3(kBlock), 0, p.c->stream, a);
+    else hipLaunchKernelGGL(k_push<double>, dim3(grid), dim3(kBlock), 0, p.c->stream, a);
     (void)ml;
     if (t->profiling && e0) { e1 = p.c->events.get(); if (e1) { hipEventRecord(e1, p.c->stream); p.comm_pairs.push_back({e0, e1}); } }
     return MI355CG_OK;
