@@ -377,7 +377,6 @@ def coordinate(args):
     my_ranks = [int(os.environ["RANK"])] if launched else list(range(world))
     local_of = {r: (int(os.environ["LOCAL_RANK"]) if launched else r) for r in my_ranks}
     lead = 0 in my_ranks
-    base_port = int(os.environ.get("MASTER_PORT", "29531")) + 101   # the launcher's own store keeps MASTER_PORT
     legs = plan_legs(args)
     results, notes = {}, []
     t_end = t_start + args.budget
@@ -390,15 +389,22 @@ def coordinate(args):
             except OSError:
                 pass
         _write_json(session, {"t_start": t_start, "pid": os.getpid()})
+        lead_start = t_start
     else:
         while time.time() < min(t_end, t_start + 90.0):
             got = _read_json(session)
             if got and abs(got["t_start"] - t_start) < 60.0:
                 t_end = got["t_start"] + args.budget                # one clock for all: the lead's
+                lead_start = got["t_start"]
                 break
             time.sleep(0.05)
         else:
             return None                                             # no lead (it failed before it got here): nothing to take part in
+
+    # The legs' rendezvous ports: above the launcher's own (MASTER_PORT stays its store's), and not the ones an invocation a few seconds
+    # ago used -- the driver runs N = 1, 2, 4, 8 back to back with one --master-port, and a port that has only just been let go of made a
+    # rendezvous take a minute in the tests.  Every coordinator derives the same numbers from the lead's start time.
+    base_port = int(os.environ.get("MASTER_PORT", "29531")) + 101 + (int(lead_start) % 97) * 8
 
     def on_term(signum, frame):
         raise _Terminated()

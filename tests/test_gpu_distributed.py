@@ -200,7 +200,7 @@ def test_bench_rehearsal_config4_shape_without_a_launcher():
     processes started by the one coordinator."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "40", "--warmup", "5", "--grid", "2048", "--scaling", "strong", "--decomp", "2d",
            "--repeats", "3", "--legs", "default"]
-    j = _bench_line(cmd, _rehearsal_env())
+    j = _bench_line(cmd, dict(_rehearsal_env(), MASTER_PORT="29931"))       # (ports of its own: the legs of the test before have only just let go of the default ones)
     assert j["n_gpus"] == 4 and j["rccl_nranks"] == 4 and j["scaling"] == "strong" and j["value"] == j["global_iters_per_sec"]
     for name in ("rccl-inline", "mailbox+push"):
         leg = j["legs"][name]
