@@ -409,7 +409,7 @@ def coordinate(args):
     def on_term(signum, frame):
         raise _Terminated()
     import threading
-    hook = lead and threading.current_thread() is threading.main_thread()
+    hook = threading.current_thread() is threading.main_thread()     # every coordinator: its rank process runs in a session of its own and has to be ended by hand
     old_term = signal.signal(signal.SIGTERM, on_term) if hook else None
 
     def kill(procs):
@@ -513,7 +513,7 @@ def coordinate(args):
             procs = []
     except _Terminated:
         kill(procs)
-        for lj in range(len(legs)):                                  # the other coordinators: this leg is over, no later one is run
+        for lj in range(len(legs) if lead else 0):                   # the other coordinators: this leg is over, no later one is run
             for suffix, obj in ((".over", {"stalled": True}), (".go", {"go": False})):
                 if not os.path.exists(os.path.join(meet, f"leg{lj}{suffix}")):
                     _write_json(os.path.join(meet, f"leg{lj}{suffix}"), obj)
@@ -688,6 +688,22 @@ def main():
 
     if args.child_leg:                                            # a rank process of one leg
         import threading
+        # Die with the coordinator, however it dies: no rank process may outlive an invocation and sit on a GPU (it runs in a session of
+        # its own, so signals to the launcher's process group pass it by).  The parent-death signal where the kernel delivers it, and a
+        # look at the parent every two seconds where it does not (it did not in the build container).
+        ppid0 = os.getppid()
+        try:
+            import ctypes
+            ctypes.CDLL(None).prctl(1, int(signal.SIGKILL))       # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
+        def orphan_watch():
+            while True:
+                time.sleep(2.0)
+                if os.getppid() != ppid0:
+                    os._exit(3)
+        threading.Thread(target=orphan_watch, daemon=True).start()
         wd = threading.Timer(args.import_allowance + args.leg_timeout + 30.0, lambda: os._exit(3))     # last resort: never outlive the coordinator's patience
         wd.daemon = True
         wd.start()
