@@ -320,7 +320,6 @@ def leg_env(base_env, spec, rank, world, local_rank, port):
                 "MI355CG_BENCH_CHILD": "1", "GLOO_SOCKET_IFNAME": env.get("GLOO_SOCKET_IFNAME", "lo"), "HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
     env.setdefault("MI355CG_TEAM_TIMEOUT_MS", "8000")   # a kernel gives a missing record 8 s, the host the stream behind it 24 s: a leg that cannot work costs half a minute, not two
     env.setdefault("GPU_MAX_HW_QUEUES", "8")           # compute, comm and side stream (+ torch's, + RCCL's) each on a hardware queue of its own: the reducer launch runs BESIDE the producer
-    env.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node: RCCL's bootstrap sockets need nothing but loopback (the box may have no other usable interface)
     for k in list(env):
         if k.startswith("TORCHELASTIC") or k in ("GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
             env.pop(k)
