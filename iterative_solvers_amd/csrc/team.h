@@ -1535,6 +1535,11 @@ int team_map_peers(mi355cg_team_s* t) {
     char why[160] = "";
     mine.ok = env_int("MI355CG_TEAM_IPC", 1) != 0 ? 1 : 0;
     if (!mine.ok) std::snprintf(why, sizeof why, "MI355CG_TEAM_IPC=0");
+    // Mapping another rank's 3.2 GB residual vector (N = 32768 cut in two) never came back from the runtime (minutes of system time;
+    // 1.6 GB -- the same grid cut in four -- maps at once).  Parts that large spend milliseconds per launch: RCCL's tens of
+    // microseconds for the records and the halo are below 1 % there, so they simply do not map.
+    const double r_gib = (double)sizeof(double) * (double)p.c->storage_len / (double)(1ull << 30);
+    if (mine.ok && r_gib > env_int("MI355CG_TEAM_IPC_MAX_GIB", 2)) { mine.ok = 0; std::snprintf(why, sizeof why, "a residual vector of %.1f GiB is not mapped (limit %d GiB)", r_gib, env_int("MI355CG_TEAM_IPC_MAX_GIB", 2)); }
     if (mine.ok) {
         hipError_t e = hipIpcGetMemHandle(&mine.slab, p.slab);
         if (e == hipSuccess) e = p.r_pooled ? hipIpcGetMemHandle(&mine.r, p.c->r) : hipErrorInvalidValue;
@@ -1591,6 +1596,9 @@ int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double
                              const void* id128, int decomp, mi355cg_team* out) {
     if (!out) return fail(MI355CG_ERR_INVALID, "out is null");
     *out = nullptr;
+    const bool dbg = env_int("MI355CG_TEAM_DEBUG", 0) != 0;                 // stage times of the creation on stderr
+    const auto dbg_t0 = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) { if (dbg) std::fprintf(stderr, "[mi355cg team rank %d +%.2f s] %s\n", rank, std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count(), what); };
     if (rank < 0 || rank >= world || !id128) return fail(MI355CG_ERR_INVALID, "bad rank %d of %d / null id", rank, world);
     if (world > kMaxRecDst) return fail(MI355CG_ERR_INVALID, "a team has at most %d parts", kMaxRecDst);
     RcclApi* api = rccl_api();
@@ -1600,8 +1608,10 @@ int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double
     t->rccl = true;
     const Box& bx = t->boxes[rank];
     TeamPart p; p.rank = rank;
+    stage("decomposition done; creating the part");
     int rc = create_impl(n, m, a, b, c_, d, MI355CG_F64, device, bx.y_lo, bx.y_hi, bx.s_lo, bx.s_hi, world > 1, &p.c);
     if (rc) { team_free(t); return rc; }
+    stage("part created (vectors, right-hand side)");
     if (world > 1) {
         // the residual vector is what the neighbours' push launches write into: it has to come from the pool (see IpcPool)
         void* pooled = nullptr;
@@ -1610,15 +1620,19 @@ int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double
         p.c->r = (double*)pooled; p.r_pooled = true;
     }
     t->parts.push_back(p);
+    stage("residual vector pooled");
     if ((rc = team_finish_setup(t))) { team_free(t); return rc; }
+    stage("halo lists, mailbox, streams");
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     if (hipSetDevice(device) != hipSuccess) { team_free(t); return fail(MI355CG_ERR_HIP, "hipSetDevice(%d) failed", device); }
     const ncclResult_t nr = api->CommInitRank(&t->comm, world, id, rank);
     if (nr != ncclSuccess) { t->comm = nullptr; team_free(t); return fail(MI355CG_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(nr)); }
     if (api->CommCount(t->comm, &t->rccl_nranks) != ncclSuccess) t->rccl_nranks = -1;
+    stage("communicator up");
     if (world > 1) {
         if ((rc = team_map_peers(t))) { team_free(t); return rc; }
+        stage("peers mapped");
         // A second communicator only where the halo is asked to travel on RCCL beside the records (MI355CG_TEAM_HALO=stream):
         // its id comes from rank 0 through the first one
         if (env_choice("MI355CG_TEAM_HALO", {"auto", "inline", "stream", "push"}, 0) == 2) {
@@ -1631,6 +1645,7 @@ int mi355cg_team_create_rccl(int n, int m, double a, double b, double c_, double
         }
     }
     if ((rc = team_build_tables(t))) { team_free(t); return rc; }
+    stage("tables built");
     *out = t;
     return MI355CG_OK;
 }

@@ -29,18 +29,19 @@ MODES = {
     "mailbox+push+split-update": {"MI355CG_TEAM_SPLIT": "2"},                                        # only the update phase in two launches: the rows leave early
     "mailbox+inline": {"MI355CG_TEAM_HALO": "inline"},
     "rccl+push": {"MI355CG_TEAM_RECORDS": "rccl", "MI355CG_TEAM_HALO": "push"},
-    "no-ipc": {"MI355CG_TEAM_IPC": "0"},                                                             # the ranks cannot map each other: falls back to RCCL for both
+    "no-ipc": {"MI355CG_TEAM_IPC": "0"},
+    "too-large-to-map": {"MI355CG_TEAM_IPC_MAX_GIB": "0"},                                           # vectors above the limit (2 GiB; here: any) are not IPC-mapped -- mapping 3 GiB never returned: RCCL for both                                                             # the ranks cannot map each other: falls back to RCCL for both
     # what ranks on GPUs of their OWN do (the default there): no stream-level waits for records, the consumer launches poll their mailboxes
     "mailbox+push+kernel-wait": {"MI355CG_TEAM_WAIT": "kernel"},
 }
 EXPECT = {
     "rccl+inline": ("rccl", "rccl-inline", 0), "rccl+stream": ("rccl", "rccl-stream", 0), "rccl+stream+split": ("rccl", "rccl-stream", 1),
     "mailbox+push": ("mailbox", "push", 0), "mailbox+push+split": ("mailbox", "push", 1), "mailbox+push+split-update": ("mailbox", "push", 2), "mailbox+inline": ("mailbox", "rccl-inline", 0),
-    "rccl+push": ("rccl", "push", 0), "no-ipc": ("rccl", "rccl-inline", 0), "mailbox+push+kernel-wait": ("mailbox", "push", 0),
+    "rccl+push": ("rccl", "push", 0), "no-ipc": ("rccl", "rccl-inline", 0), "too-large-to-map": ("rccl", "rccl-inline", 0), "mailbox+push+kernel-wait": ("mailbox", "push", 0),
 }
 for _name in filter(None, os.environ.get("MI355CG_TEST_EXTRA_MODES", "").split(",")):      # tools/dbg_modes.py: "mailbox+push#3" = a further run of that mode
     MODES[_name], EXPECT[_name] = MODES[_name.split("#")[0]], EXPECT[_name.split("#")[0]]
-KEYS = ("MI355CG_TEAM_RECORDS", "MI355CG_TEAM_HALO", "MI355CG_TEAM_SPLIT", "MI355CG_TEAM_IPC", "MI355CG_TEAM_WAIT")
+KEYS = ("MI355CG_TEAM_RECORDS", "MI355CG_TEAM_HALO", "MI355CG_TEAM_SPLIT", "MI355CG_TEAM_IPC", "MI355CG_TEAM_WAIT", "MI355CG_TEAM_IPC_MAX_GIB")
 
 
 def _params(isa, rule, **kw):
@@ -179,7 +180,9 @@ def _check(parts, ref, world, modes, real=False):
                 assert d[1] == "kernel" and int(d[5]) == 0 and int(d[6]) == world and d[7].startswith("librccl")     # a GPU each: kernels poll, RCCL is RCCL
             else:
                 assert d[1] == ("kernel" if "kernel-wait" in mode else "stream") and int(d[5]) == 1     # the ranks found out that they share one GPU: no polling kernels unless asked for
-                assert int(d[4]) == (0 if mode == "no-ipc" else 1) and int(d[6]) == world and d[7].endswith("libnccl_shim.so")
+                assert int(d[4]) == (0 if mode in ("no-ipc", "too-large-to-map") else 1) and int(d[6]) == world and d[7].endswith("libnccl_shim.so")
+                if mode == "too-large-to-map":
+                    assert "not_mapped" in d[8]
             it, conv, reason, rn, r0 = p[f"{mode}/rel"]
             assert (it, conv, reason) == (ref["rel"].iterations, ref["rel"].converged, ref["rel"].stop_reason), (mode, rank)
             assert rn == ref["rel"].r_norm2 and r0 == ref["rel"].initial_r_norm2, (mode, rank)
