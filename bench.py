@@ -427,6 +427,7 @@ def coordinate(args):
                 log.close()
 
     procs = []
+    mailbox_broken = None                                           # the first leg of the mailbox transport that stalled or failed
     try:
         for li, spec in enumerate(legs):
             local = spec["driver"] == "local"
@@ -439,7 +440,18 @@ def coordinate(args):
                 go = left >= min(45.0, args.leg_timeout) or not results
                 if not go:
                     notes.append(f"leg {spec['name']} not started: {left:.0f} s left of the {args.budget:.0f} s budget")
-                _write_json(tag + ".go", {"go": go})
+                # Once the mailbox transport has failed on this node (a leg that stalled or ended in an error), its variants would only
+                # repeat that at a leg's time limit each: the other headline variants are skipped, and the sub-records (BASELINE's own
+                # configurations) run on the order-safe RCCL schedule instead.
+                swap = None
+                if go and mailbox_broken and spec["transport"].startswith("mailbox+push") and not local:
+                    if spec["headline"]:
+                        go = False
+                        notes.append(f"leg {spec['name']} not started: the mailbox transport failed in leg {mailbox_broken}")
+                    else:
+                        swap = "rccl-inline"
+                        notes.append(f"leg {spec['name']} runs on rccl-inline: the mailbox transport failed in leg {mailbox_broken}")
+                _write_json(tag + ".go", {"go": go, "transport": swap})
             else:
                 got = None
                 while got is None and time.time() < t_end:
@@ -449,8 +461,11 @@ def coordinate(args):
                 go = bool(got and got["go"])
                 if got is None:
                     return None
+                swap = got.get("transport")
             if not go:
                 continue
+            if swap:
+                spec = dict(spec, transport=swap)
             ranks = [0] if local else my_ranks
             need = [0] if local else list(range(world))
             out_path = tag
@@ -509,6 +524,8 @@ def coordinate(args):
                 rec["what"] = TRANSPORTS.get(spec["transport"], (None, "one process drives all parts (LOCAL transport: peer access, one host thread per device)"))[1]
                 rec["headline_candidate"] = bool(spec["headline"])
                 results[spec["name"]] = rec
+                if "error" in rec and spec["transport"].startswith("mailbox+push") and not local and not mailbox_broken:
+                    mailbox_broken = spec["name"]
             procs = []
     except _Terminated:
         kill(procs)

@@ -69,6 +69,8 @@ if os.environ.get("STUB_NEVER_READY") == "1":
     time.sleep(600)
 open(out + ".r%d.ready" % rank, "w").close()
 time.sleep(float(os.environ.get("STUB_WORK_S", "0")))
+if spec["name"] == "mailbox+push" and os.environ.get("STUB_PUSH_FAIL") == "1":
+    json.dump({"leg": spec["name"], "error": "rank %d: the mapping never came back" % rank}, open(out + ".r%d" % rank, "w")); sys.exit(1)
 if spec["name"] == "rccl-stream":
     time.sleep(600)                                    # a collective that never completes
 if spec["name"] == "config5-strong-32768" and rank == world - 1:
@@ -195,3 +197,26 @@ def test_sigterm_still_prints_the_line(stub, tmp_path):
     procs[0].send_signal(signal.SIGTERM)
     out = _collect(procs, timeout=90)
     assert out["value"] == 50000.0 and out["headline_leg"] == "rccl-inline" and any("SIGTERM" in n for n in out["notes"])
+
+
+def test_a_failed_mailbox_leg_spares_its_variants_and_reroutes_the_sub_records(stub, monkeypatch):
+    """The mailbox transport fails on this node (first leg that uses it): its headline variants are not started (each would repeat the
+    failure at a leg's time limit), BASELINE's configurations run on the order-safe RCCL schedule instead, the line carries the notes."""
+    monkeypatch.setenv("STUB_PUSH_FAIL", "1")
+    args = _args(gpus=4, leg_timeout=3.0, legs="rccl-inline,mailbox+push,mailbox+push+split-update,mailbox+push+split,config5-strong-32768,config4-2x2-16384,local-one-process")
+    legs, results, notes = bench.coordinate(args)
+    assert "never came back" in results["mailbox+push"]["error"]
+    assert "mailbox+push+split-update" not in results and "mailbox+push+split" not in results
+    assert results["config4-2x2-16384"]["transport"]["records"] == "rccl"                 # the rank processes got the RCCL schedule's environment
+    assert "ncclAllGather" in results["config5-strong-32768"]["what"] and "ncclAllGather" in results["config4-2x2-16384"]["what"]
+    assert results["local-one-process"]["n_gpus"] == 1
+    assert sum("the mailbox transport failed in leg mailbox+push" in n for n in notes) == 4
+    out = bench.compose(args, legs, results, notes)
+    assert out["headline_leg"] == "rccl-inline" and out["value"] == 50000.0
+
+
+def test_the_reroute_reaches_every_coordinator(stub, tmp_path):
+    out = _collect(_launch_workers(tmp_path, stub, 4, 29840, extra_env={"STUB_PUSH_FAIL": "1"}, legs="rccl-inline,mailbox+push,mailbox+push+split,config4-2x2-16384", leg_timeout=4.0, import_allowance=5.0))
+    assert "never came back" in out["legs"]["mailbox+push"]["error"] and "mailbox+push+split" not in out["legs"]
+    assert out["legs"]["config4-2x2-16384"]["transport"]["records"] == "rccl" and out["legs"]["config4-2x2-16384"]["n_gpus"] == 4    # all four rank processes ran the RCCL schedule
+    assert out["headline_leg"] == "rccl-inline" and len(out["notes"]) == 2
