@@ -1537,9 +1537,10 @@ int team_map_peers(mi355cg_team_s* t) {
     if (!mine.ok) std::snprintf(why, sizeof why, "MI355CG_TEAM_IPC=0");
     // Mapping another rank's 3.2 GB residual vector (N = 32768 cut in two) never came back from the runtime (minutes of system time;
     // 1.6 GB -- the same grid cut in four -- maps at once).  Parts that large spend milliseconds per launch: RCCL's tens of
-    // microseconds for the records and the halo are below 1 % there, so they simply do not map.
+    // microseconds for the records and the halo are below 1 % there, so they simply do not map.  (>=: 2^31 bytes is where a signed
+    // 32-bit size would turn over.)
     const double r_gib = (double)sizeof(double) * (double)p.c->storage_len / (double)(1ull << 30);
-    if (mine.ok && r_gib >= env_int("MI355CG_TEAM_IPC_MAX_GIB", 2)) {      // (>=: 2^31 bytes is where a signed 32-bit size would turn over) mine.ok = 0; std::snprintf(why, sizeof why, "a residual vector of %.1f GiB is not mapped (limit %d GiB)", r_gib, env_int("MI355CG_TEAM_IPC_MAX_GIB", 2)); }
+    if (mine.ok && r_gib >= env_int("MI355CG_TEAM_IPC_MAX_GIB", 2)) { mine.ok = 0; std::snprintf(why, sizeof why, "a residual vector of %.1f GiB is not mapped (limit %d GiB)", r_gib, env_int("MI355CG_TEAM_IPC_MAX_GIB", 2)); }
     if (mine.ok) {
         hipError_t e = hipIpcGetMemHandle(&mine.slab, p.slab);
         if (e == hipSuccess) e = p.r_pooled ? hipIpcGetMemHandle(&mine.r, p.c->r) : hipErrorInvalidValue;
